@@ -1,0 +1,132 @@
+/* kvc.h — C-ABI of the MI355X (gfx950) KV-cache compression hot path.
+ *
+ * Drop-in boundary for ONE path of assassin808/KVCache-Factory (reference @ 2025-02-18): the
+ * post-prefill scoring + eviction step behind `kv_cluster.update_kv(key_states, query_states,
+ * value_states, attention_mask, num_key_value_groups)`:
+ *     SnapKVCluster.update_kv          pyramidkv/pyramidkv_utils.py:306-347
+ *     PyramidKVCluster.update_kv       pyramidkv/pyramidkv_utils.py:197-283
+ *     H2OKVCluster.update_kv           pyramidkv/pyramidkv_utils.py:533-575
+ *     StreamingLLMKVCluster.update_kv  pyramidkv/pyramidkv_utils.py:595-620
+ * The reference has no C/FFI interface on this path (it is ~60 lines of torch ops per method);
+ * these entry points are what a ctypes binding of `update_kv` binds (INTEGRATION.md shows the
+ * stub).  Implemented in kvcache_factory_amd/csrc/ (hand-written HIP, libkvc_hip.so).
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer (HBM), 16-byte aligned; nothing is copied to the host;
+ *   - the library never allocates device memory, never synchronises the stream and never throws:
+ *     all kernels are enqueued on `hip_stream` (a hipStream_t, NULL = default stream);
+ *   - tensors are indexed [b][h][l][d] with d contiguous and element strides given in the params;
+ *   - outputs are dense: k_out/v_out [bsz][n_q_heads][k+window][head_dim] in the input dtype,
+ *     idx_out [bsz][n_q_heads][k] int64 (value-descending order, like torch.topk), scores_out
+ *     [bsz][n_q_heads][q_len-window] in the input dtype (the pooled scores of :328-333);
+ *   - return value 0 on success, negative kvc_status otherwise; kvc_last_error() gives the text.
+ */
+#ifndef KVC_H_
+#define KVC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KVC_VERSION 1
+
+typedef enum kvc_status {
+    KVC_OK = 0,
+    KVC_ERR_INVALID = -1,      /* the reference would assert / raise (pyramidkv_utils.py:289,309,333) */
+    KVC_ERR_UNSUPPORTED = -2,  /* valid for the reference, not implemented by this library (documented limits) */
+    KVC_ERR_WORKSPACE = -3,    /* workspace missing, misaligned or smaller than kvc_workspace_bytes() */
+    KVC_ERR_ALIGNMENT = -4,    /* a pointer or stride is not 16-byte aligned */
+    KVC_ERR_HIP = -5           /* a HIP runtime call failed (message carries hipGetErrorString) */
+} kvc_status;
+
+typedef enum kvc_method {      /* which update_kv is being replaced */
+    KVC_SNAPKV = 0,            /* pyramidkv_utils.py:306-347 */
+    KVC_PYRAMIDKV = 1,         /* :197-283 — same kernels, caller passes the per-layer k (kvc_pyramid_k) */
+    KVC_H2O = 2,               /* :533-575 — all q_len query rows, no pooling */
+    KVC_STREAMINGLLM = 3       /* :595-620 — no scoring: first k + last window tokens */
+} kvc_method;
+
+typedef enum kvc_dtype { KVC_BF16 = 0, KVC_FP16 = 1, KVC_FP32 = 2 } kvc_dtype;
+typedef enum kvc_pooling { KVC_POOL_NONE = 0, KVC_POOL_AVG = 1, KVC_POOL_MAX = 2 } kvc_pooling;
+
+typedef enum kvc_tie_mode {
+    KVC_TIES_TORCH_CPU = 0,    /* membership and order of equal scores exactly as torch-CPU topk
+                                  (libstdc++ partial_sort when k*64<=n, else nth_element+sort) */
+    KVC_TIES_CANONICAL = 1     /* value descending, index ascending (fast path) */
+} kvc_tie_mode;
+
+typedef struct kvc_params {
+    int32_t method;            /* kvc_method */
+    int32_t dtype;             /* kvc_dtype of q, k, v and of every non-index output */
+    int32_t bsz;               /* batch (the reference runs bsz = 1, README.md:29; code is batch-agnostic) */
+    int32_t n_q_heads;         /* heads of q and of the outputs (32 for Llama-3-8B / Mistral-7B) */
+    int32_t n_kv_heads;        /* heads present in k and v: n_q_heads when the caller passes the
+                                  repeat_kv()-expanded tensors like the reference (llama_model.py:277-278),
+                                  or the model's KV heads (8) to read each KV head once.  Query head h
+                                  reads kv head h / (n_q_heads / n_kv_heads). */
+    int32_t q_len;             /* L: key_states.shape[-2] == query_states.shape[-2] (:309) */
+    int32_t head_dim;          /* D: 64 or 128 */
+    int32_t window;            /* W = window_size: the last W queries score, the last W tokens are kept */
+    int32_t k;                 /* prefix tokens kept per head: max_capacity_prompt - W (:334), or the
+                                  PyramidKV per-layer budget (:214); 0 <= k <= L - W */
+    int32_t kernel_size;       /* pooling kernel (odd; padding = kernel_size/2, stride 1) (:328-333) */
+    int32_t pooling;           /* kvc_pooling; ignored for H2O (no pooling, :555-561) and StreamingLLM */
+    int32_t tie_mode;          /* kvc_tie_mode */
+    int32_t reserved0, reserved1;
+    int64_t q_stride_b, q_stride_h, q_stride_l;   /* element strides of q[b][h][l][:] */
+    int64_t k_stride_b, k_stride_h, k_stride_l;
+    int64_t v_stride_b, v_stride_h, v_stride_l;
+} kvc_params;
+
+/* Library / ABI version (== KVC_VERSION). */
+int kvc_version(void);
+
+/* Thread-local text of the last error returned on this thread ("" if none). */
+const char* kvc_last_error(void);
+
+/* Bytes of device scratch kvc_compress / kvc_scores / kvc_select need for these params
+ * (0 for StreamingLLM).  Returns 0 and sets the error text if the params are invalid. */
+size_t kvc_workspace_bytes(const kvc_params* p);
+
+/* The whole update_kv: scores (A1-A5, or A10 for H2O) -> per-head top-k (A7) -> gather + window
+ * tail (A8), for the method in p->method.  Replaces the body of
+ *   SnapKVCluster.update_kv :317-346 / PyramidKVCluster.update_kv :220-283 /
+ *   H2OKVCluster.update_kv :544-575 / StreamingLLMKVCluster.update_kv :607-620.
+ * q: full query tensor base (row L-W.. are read; every row for H2O; ignored for StreamingLLM).
+ * idx_out and scores_out may be NULL (scores_out is never written for StreamingLLM). */
+int kvc_compress(const kvc_params* p, const void* q, const void* k, const void* v,
+                 void* k_out, void* v_out, int64_t* idx_out, void* scores_out,
+                 void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Stage entry points (same kernels kvc_compress enqueues), exposed so parity can be pinned stage by stage. */
+
+/* A1-A5 (A10 for H2O): pooled scores [bsz][n_q_heads][L-W] in dtype (:317-333 / :544-561). */
+int kvc_scores(const kvc_params* p, const void* q, const void* k, void* scores_out,
+               void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* A7: idx_out[b][h][0..k) = topk(scores[b][h][0..L-W), k).indices (:334). */
+int kvc_select(const kvc_params* p, const void* scores, int64_t* idx_out,
+               void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* A8 for one tensor: out[b][h] = cat(src[b][h/g][idx[b][h][:]], src[b][h/g][L-W:]) (:341-346).
+ * idx == NULL means idx[t] = t (StreamingLLM, :607-608).  Strides are those of `src`. */
+int kvc_gather(const kvc_params* p, const void* src, int64_t stride_b, int64_t stride_h, int64_t stride_l,
+               const int64_t* idx, void* out, void* hip_stream);
+
+/* PyramidKV per-layer budget, host arithmetic only (:205-215, beta = 20 at :174).
+ * Returns the k for `layer_idx`; -1 means "pass-through" (q_len < cap, :218). */
+int64_t kvc_pyramid_k(int64_t max_capacity_prompt, int64_t window, int64_t q_len,
+                      int64_t layer_idx, int64_t num_hidden_layers, int64_t beta);
+
+/* Debug/parity aid: byte offsets inside the workspace of the intermediates kvc_scores leaves behind.
+ * offs[0]=logits [b][h][L][W] dtype, offs[1]=row max [b][h][W] f32, offs[2]=row sum [b][h][W] f32.
+ * Returns KVC_OK or an error. */
+int kvc_workspace_layout(const kvc_params* p, size_t offs[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KVC_H_ */

@@ -1,0 +1,221 @@
+"""ctypes binding of libkvc_hip.so (C-ABI: include/kvc.h).  PyTorch is used only for device memory
+and the current HIP stream.  Fails loudly when the extension is absent — there is no fallback."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkvc_hip.so")
+
+SNAPKV, PYRAMIDKV, H2O, STREAMINGLLM = 0, 1, 2, 3
+BF16, FP16, FP32 = 0, 1, 2
+POOL_NONE, POOL_AVG, POOL_MAX = 0, 1, 2
+TIES_TORCH_CPU, TIES_CANONICAL = 0, 1
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_ALIGNMENT, ERR_HIP = 0, -1, -2, -3, -4, -5
+
+DTYPES = {torch.bfloat16: BF16, torch.float16: FP16, torch.float32: FP32}
+POOLINGS = {"avgpool": POOL_AVG, "maxpool": POOL_MAX, None: POOL_NONE, "none": POOL_NONE}
+TIE_MODES = {"torch_cpu": TIES_TORCH_CPU, "canonical": TIES_CANONICAL}
+
+EXPORTS = ("kvc_version", "kvc_last_error", "kvc_workspace_bytes", "kvc_compress", "kvc_scores", "kvc_select",
+           "kvc_gather", "kvc_pyramid_k", "kvc_workspace_layout")
+
+
+class KvcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"kvc error {code}: {msg}")
+        self.code = code
+
+
+class Params(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "method", "dtype", "bsz", "n_q_heads", "n_kv_heads", "q_len", "head_dim", "window", "k",
+        "kernel_size", "pooling", "tie_mode", "reserved0", "reserved1")] + [
+        (n, ctypes.c_int64) for n in (
+            "q_stride_b", "q_stride_h", "q_stride_l", "k_stride_b", "k_stride_h", "k_stride_l",
+            "v_stride_b", "v_stride_h", "v_stride_l")]
+
+
+_lib = None
+
+
+def lib():
+    """Load libkvc_hip.so.  Raises if it has not been built (python __graft_entry__.py / make -C csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make -C kvcache_factory_amd/csrc` "
+                "(there is no CPU or PyTorch fallback for this path)")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, pp, sz = ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_size_t
+        L.kvc_version.restype = ctypes.c_int
+        L.kvc_last_error.restype = ctypes.c_char_p
+        L.kvc_workspace_bytes.argtypes = [pp]
+        L.kvc_workspace_bytes.restype = sz
+        L.kvc_compress.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+        L.kvc_scores.argtypes = [pp, vp, vp, vp, vp, sz, vp]
+        L.kvc_select.argtypes = [pp, vp, vp, vp, sz, vp]
+        L.kvc_gather.argtypes = [pp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, vp]
+        L.kvc_pyramid_k.argtypes = [ctypes.c_int64] * 6
+        L.kvc_pyramid_k.restype = ctypes.c_int64
+        L.kvc_workspace_layout.argtypes = [pp, ctypes.POINTER(sz * 3)]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise KvcError(rc, lib().kvc_last_error().decode())
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_workspaces = {}
+
+
+def workspace(device, nbytes):
+    """Grow-only per-(device, stream) scratch; reuse is safe because every user is stream-ordered."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _last_dim_contig(t):
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+def make_params(method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu"):
+    ref = k if k is not None else q
+    p = Params()
+    p.method = method
+    p.dtype = DTYPES[ref.dtype]
+    p.bsz = ref.shape[0]
+    p.n_q_heads = q.shape[1] if q is not None else ref.shape[1]
+    p.n_kv_heads = k.shape[1] if k is not None else p.n_q_heads
+    p.q_len, p.head_dim = ref.shape[2], ref.shape[3]
+    p.window, p.k = window, n_keep
+    p.kernel_size = kernel_size
+    if pooling not in POOLINGS:
+        raise ValueError('Pooling method not supported')      # pyramidkv_utils.py:333
+    p.pooling = POOLINGS[pooling]
+    p.tie_mode = TIE_MODES[tie_mode] if isinstance(tie_mode, str) else tie_mode
+    if q is not None:
+        p.q_stride_b, p.q_stride_h, p.q_stride_l = q.stride(0), q.stride(1), q.stride(2)
+    if k is not None:
+        p.k_stride_b, p.k_stride_h, p.k_stride_l = k.stride(0), k.stride(1), k.stride(2)
+    if v is not None:
+        p.v_stride_b, p.v_stride_h, p.v_stride_l = v.stride(0), v.stride(1), v.stride(2)
+    return p
+
+
+def _require_gpu(*ts):
+    for t in ts:
+        if t is not None and t.device.type != "cuda":
+            raise RuntimeError("kvcache_factory_amd runs on the GPU only (HIP kernels); got a %s tensor — "
+                               "there is no CPU fallback" % t.device.type)
+
+
+def compress(method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu",
+             n_q_heads=None, return_indices=False, return_scores=False):
+    """One update_kv body on the GPU: returns (k_out, v_out[, idx][, scores])."""
+    _require_gpu(q, k, v)
+    k, v = _last_dim_contig(k), _last_dim_contig(v)
+    if q is not None:
+        q = _last_dim_contig(q)
+    dev = k.device
+    if method == STREAMINGLLM:
+        hq = n_q_heads if n_q_heads is not None else (q.shape[1] if q is not None else k.shape[1])
+        p = make_params(method, None, k, v, window, n_keep, kernel_size, None, tie_mode)
+        p.n_q_heads = hq
+        qq = None
+    else:
+        p = make_params(method, q, k, v, window, n_keep, kernel_size, pooling, tie_mode)
+        hq, qq = q.shape[1], q
+    bsz, L, D = k.shape[0], k.shape[2], k.shape[3]
+    k_out = torch.empty(bsz, hq, n_keep + window, D, dtype=k.dtype, device=dev)
+    v_out = torch.empty_like(k_out)
+    scoring = method != STREAMINGLLM
+    idx = torch.empty(bsz, hq, n_keep, dtype=torch.int64, device=dev) if (return_indices and scoring) else None
+    sc = torch.empty(bsz, hq, L - window, dtype=k.dtype, device=dev) if (return_scores and scoring) else None
+    nbytes = lib().kvc_workspace_bytes(ctypes.byref(p))
+    if nbytes == 0 and scoring:
+        _check(lib().kvc_scores(ctypes.byref(p), None, None, None, None, 0, None) or ERR_INVALID)
+    ws = workspace(dev, nbytes) if nbytes else None
+    _check(lib().kvc_compress(ctypes.byref(p), _ptr(qq), _ptr(k), _ptr(v), _ptr(k_out), _ptr(v_out), _ptr(idx),
+                              _ptr(sc), _ptr(ws), nbytes, _stream(dev)))
+    out = [k_out, v_out]
+    if return_indices:
+        if not scoring:
+            idx = torch.arange(n_keep, device=dev).expand(bsz, hq, n_keep).contiguous()
+        out.append(idx)
+    if return_scores:
+        out.append(sc)
+    return tuple(out)
+
+
+def scores(method, q, k, window, kernel_size=5, pooling="avgpool", want_intermediates=False):
+    """Stage A1-A5 only.  Returns pooled scores [bsz,Hq,L-W] (+ logits [bsz,Hq,L,W], rowmax, rowsum)."""
+    _require_gpu(q, k)
+    q, k = _last_dim_contig(q), _last_dim_contig(k)
+    p = make_params(method, q, k, None, window, 0, kernel_size, pooling)
+    bsz, hq, L = q.shape[0], q.shape[1], q.shape[2]
+    sc = torch.empty(bsz, hq, L - window, dtype=q.dtype, device=q.device)
+    nbytes = lib().kvc_workspace_bytes(ctypes.byref(p))
+    if nbytes == 0:
+        _check(lib().kvc_scores(ctypes.byref(p), None, None, None, None, 0, None) or ERR_INVALID)
+    ws = workspace(q.device, nbytes)
+    _check(lib().kvc_scores(ctypes.byref(p), _ptr(q), _ptr(k), _ptr(sc), _ptr(ws), nbytes, _stream(q.device)))
+    if not want_intermediates:
+        return sc
+    offs = (ctypes.c_size_t * 3)()
+    _check(lib().kvc_workspace_layout(ctypes.byref(p), ctypes.byref(offs)))
+    es = q.element_size()
+    nlog = bsz * hq * L * window
+    logits = ws[offs[0]:offs[0] + nlog * es].view(q.dtype).view(bsz, hq, L, window).clone()
+    rowmax = ws[offs[1]:offs[1] + bsz * hq * window * 4].view(torch.float32).view(bsz, hq, window).clone()
+    rowsum = ws[offs[2]:offs[2] + bsz * hq * window * 4].view(torch.float32).view(bsz, hq, window).clone()
+    return sc, logits, rowmax, rowsum
+
+
+def select(scores_t, n_keep, tie_mode="torch_cpu"):
+    """Stage A7 only: scores [bsz,H,n] -> indices int64 [bsz,H,k]."""
+    _require_gpu(scores_t)
+    assert scores_t.dim() == 3 and scores_t.is_contiguous()
+    p = Params()
+    p.method, p.dtype = SNAPKV, DTYPES[scores_t.dtype]
+    p.bsz, p.n_q_heads, p.n_kv_heads = scores_t.shape[0], scores_t.shape[1], scores_t.shape[1]
+    p.window, p.head_dim, p.q_len, p.k = 1, 8, scores_t.shape[2] + 1, n_keep
+    p.pooling = POOL_NONE
+    p.tie_mode = TIE_MODES[tie_mode] if isinstance(tie_mode, str) else tie_mode
+    idx = torch.empty(scores_t.shape[0], scores_t.shape[1], n_keep, dtype=torch.int64, device=scores_t.device)
+    _check(lib().kvc_select(ctypes.byref(p), _ptr(scores_t), _ptr(idx), None, 0, _stream(scores_t.device)))
+    return idx
+
+
+def gather(src, idx, window, n_q_heads):
+    """Stage A8 only for one tensor: src [bsz,Hs,L,D], idx [bsz,Hq,k] or None -> [bsz,Hq,k+W,D]."""
+    _require_gpu(src, idx)
+    src = _last_dim_contig(src)
+    n_keep = idx.shape[2] if idx is not None else 0
+    p = make_params(SNAPKV, None, src, None, window, n_keep, 1, None)
+    p.n_q_heads = n_q_heads
+    out = torch.empty(src.shape[0], n_q_heads, n_keep + window, src.shape[3], dtype=src.dtype, device=src.device)
+    _check(lib().kvc_gather(ctypes.byref(p), _ptr(src), src.stride(0), src.stride(1), src.stride(2),
+                            _ptr(idx.contiguous() if idx is not None else None), _ptr(out), _stream(src.device)))
+    return out
+
+
+def pyramid_k(cap, window, q_len, layer_idx, n_layers, beta=20):
+    """PyramidKV per-layer budget (pyramidkv_utils.py:205-215): k, or -1 for pass-through."""
+    return int(lib().kvc_pyramid_k(cap, window, q_len, layer_idx, n_layers, beta))

@@ -1,0 +1,253 @@
+// kvc_api.hip — the C-ABI of include/kvc.h: validation, workspace carving and kernel enqueue.
+// Nothing here allocates device memory, synchronises, or touches the host copy of any tensor.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "kvc_common.h"
+#include "kvc_launch.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline int esize_of(int dtype) { return dtype == KVC_FP32 ? 4 : 2; }
+inline bool scoring(int method) { return method == KVC_SNAPKV || method == KVC_PYRAMIDKV || method == KVC_H2O; }
+
+struct Layout {
+    size_t logits, pmax, psum, rowmax, rowsum, scores, idx, total;
+    int n_tiles, n_chunks;
+};
+
+// Validation shared by every entry point.  `need_q`: the call reads q/k for scoring.
+int validate(const kvc_params* p, bool need_scores) {
+    if (!p) return fail(KVC_ERR_INVALID, "params is NULL");
+    if (p->method < KVC_SNAPKV || p->method > KVC_STREAMINGLLM) return fail(KVC_ERR_INVALID, "unknown method %d", p->method);
+    if (p->dtype < KVC_BF16 || p->dtype > KVC_FP32) return fail(KVC_ERR_INVALID, "unknown dtype %d", p->dtype);
+    if (p->bsz < 1 || p->n_q_heads < 1 || p->n_kv_heads < 1) return fail(KVC_ERR_INVALID, "bsz / head counts must be positive");
+    if (p->n_q_heads % p->n_kv_heads) return fail(KVC_ERR_INVALID, "n_q_heads %d not a multiple of n_kv_heads %d", p->n_q_heads, p->n_kv_heads);
+    if (p->window < 1) return fail(KVC_ERR_INVALID, "window must be >= 1");
+    if (p->q_len <= p->window) return fail(KVC_ERR_INVALID, "q_len %d must exceed window %d", p->q_len, p->window);
+    if (p->k < 0 || p->k > p->q_len - p->window)
+        return fail(KVC_ERR_INVALID, "k=%d outside [0, q_len-window=%d] (reference: topk k out of range)", p->k, p->q_len - p->window);
+    const int es = esize_of(p->dtype);
+    if (p->head_dim < 1 || (p->head_dim * es) % 16) return fail(KVC_ERR_UNSUPPORTED, "head_dim*esize must be a multiple of 16 bytes");
+    if (p->head_dim * es > 4096) return fail(KVC_ERR_UNSUPPORTED, "head_dim too large");
+    if (p->tie_mode != KVC_TIES_TORCH_CPU && p->tie_mode != KVC_TIES_CANONICAL) return fail(KVC_ERR_INVALID, "unknown tie_mode %d", p->tie_mode);
+    if (need_scores && scoring(p->method)) {
+        if (p->head_dim != 64 && p->head_dim != 128) return fail(KVC_ERR_UNSUPPORTED, "scoring kernels are built for head_dim 64 and 128, got %d", p->head_dim);
+        if (p->window > 64) return fail(KVC_ERR_UNSUPPORTED, "scoring window %d > 64 not built", p->window);
+        if (p->method != KVC_H2O) {
+            if (p->pooling != KVC_POOL_AVG && p->pooling != KVC_POOL_MAX && p->pooling != KVC_POOL_NONE)
+                return fail(KVC_ERR_INVALID, "Pooling method not supported");   // pyramidkv_utils.py:333
+            if (p->pooling != KVC_POOL_NONE) {
+                if (p->kernel_size < 1 || p->kernel_size > 63) return fail(KVC_ERR_UNSUPPORTED, "kernel_size %d outside [1,63]", p->kernel_size);
+                if ((p->kernel_size & 1) == 0)
+                    return fail(KVC_ERR_UNSUPPORTED, "even kernel_size %d: the reference's pooled length becomes n+1 and its gather can index out of range", p->kernel_size);
+            }
+        }
+    }
+    return KVC_OK;
+}
+
+int check_strides(const char* what, int es, int64_t sb, int64_t sh, int64_t sl, const void* ptr) {
+    if (((uintptr_t)ptr) % 16) return fail(KVC_ERR_ALIGNMENT, "%s pointer not 16-byte aligned", what);
+    if ((sb * es) % 16 || (sh * es) % 16 || (sl * es) % 16) return fail(KVC_ERR_ALIGNMENT, "%s strides not multiples of 16 bytes", what);
+    return KVC_OK;
+}
+
+Layout carve(const kvc_params* p) {
+    Layout l;
+    std::memset(&l, 0, sizeof(l));
+    const size_t es = (size_t)esize_of(p->dtype);
+    const size_t heads = (size_t)p->bsz * p->n_q_heads, L = (size_t)p->q_len, W = (size_t)p->window, n = L - W;
+    l.n_tiles = (int)((L + 127) / 128);
+    l.n_chunks = (int)((L + 255) / 256);
+    size_t off = 0;
+    if (scoring(p->method)) {
+        l.logits = off; off = align_up(off + heads * L * W * es, 256);
+        l.pmax = off;   off = align_up(off + heads * (size_t)l.n_tiles * W * 4, 256);
+        l.psum = off;   off = align_up(off + heads * (size_t)l.n_chunks * W * 4, 256);
+        l.rowmax = off; off = align_up(off + heads * W * 4, 256);
+        l.rowsum = off; off = align_up(off + heads * W * 4, 256);
+        l.scores = off; off = align_up(off + heads * n * es, 256);
+        l.idx = off;    off = align_up(off + heads * (size_t)p->k * 8, 256);
+    }
+    l.total = off;
+    return l;
+}
+
+int check_ws(const Layout& l, void* ws, size_t bytes) {
+    if (l.total == 0) return KVC_OK;
+    if (!ws) return fail(KVC_ERR_WORKSPACE, "workspace is NULL, need %zu bytes", l.total);
+    if (((uintptr_t)ws) % 256) return fail(KVC_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    if (bytes < l.total) return fail(KVC_ERR_WORKSPACE, "workspace too small: %zu < %zu", bytes, l.total);
+    return KVC_OK;
+}
+
+int hip_ok(const char* where) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(KVC_ERR_HIP, "%s: %s", where, hipGetErrorString(e));
+    return KVC_OK;
+}
+
+int enqueue_scores(const kvc_params* p, const Layout& l, const void* q, const void* k, void* scores, char* ws, hipStream_t st) {
+    if (p->method == KVC_H2O) return fail(KVC_ERR_UNSUPPORTED, "H2O scoring kernel not built yet");
+    kvc::ScoreArgs a;
+    a.q = q; a.k = k;
+    a.logits = ws + l.logits;
+    a.pmax = reinterpret_cast<float*>(ws + l.pmax);
+    a.psum = reinterpret_cast<float*>(ws + l.psum);
+    a.rowmax = reinterpret_cast<float*>(ws + l.rowmax);
+    a.rowsum = reinterpret_cast<float*>(ws + l.rowsum);
+    a.scores = scores;
+    a.q_stride_b = p->q_stride_b; a.q_stride_h = p->q_stride_h; a.q_stride_l = p->q_stride_l;
+    a.k_stride_b = p->k_stride_b; a.k_stride_h = p->k_stride_h; a.k_stride_l = p->k_stride_l;
+    a.bsz = p->bsz; a.n_q_heads = p->n_q_heads; a.n_kv_heads = p->n_kv_heads;
+    a.group = p->n_q_heads / p->n_kv_heads;
+    a.q_len = p->q_len; a.window = p->window;
+    a.n_tiles = l.n_tiles; a.n_chunks = l.n_chunks;
+    a.kernel_size = p->kernel_size; a.pooling = p->pooling;
+    a.sqrt_d = (float)std::sqrt((double)p->head_dim);   // math.sqrt(head_dim) -> fp32 (pyramidkv_utils.py:317)
+    const int rc = kvc::launch_scores(a, p->dtype, p->head_dim, st);
+    if (rc) return fail(rc, "no scoring kernel for dtype %d head_dim %d", p->dtype, p->head_dim);
+    return hip_ok("scores launch");
+}
+
+int enqueue_select(const kvc_params* p, const void* scores, int64_t* idx, hipStream_t st) {
+    if (p->k == 0) return KVC_OK;
+    if (p->k > 16384) return fail(KVC_ERR_UNSUPPORTED, "k=%d > 16384: the LDS sort of the selected set is not built for it", p->k);
+    kvc::SelectArgs s;
+    s.scores = scores; s.idx = idx;
+    s.n = p->q_len - p->window; s.k = p->k; s.heads = p->bsz * p->n_q_heads;
+    s.pow2 = 1;
+    while (s.pow2 < s.k) s.pow2 <<= 1;
+    const int rc = kvc::launch_select(s, p->dtype, p->tie_mode, st);
+    if (rc == KVC_ERR_UNSUPPORTED) return fail(rc, "tie_mode %d not built for this shape", p->tie_mode);
+    if (rc) return fail(rc, "select launch failed");
+    return hip_ok("select launch");
+}
+
+int enqueue_gather(const kvc_params* p, const void* src, int64_t sb, int64_t sh, int64_t sl, const int64_t* idx, void* out, hipStream_t st) {
+    kvc::GatherArgs g;
+    g.src = src; g.out = out; g.idx = idx;
+    g.stride_b = sb; g.stride_h = sh; g.stride_l = sl;
+    g.bsz = p->bsz; g.n_q_heads = p->n_q_heads; g.group = p->n_q_heads / p->n_kv_heads;
+    g.q_len = p->q_len; g.window = p->window; g.k = p->k;
+    g.esize = esize_of(p->dtype);
+    g.row_bytes = p->head_dim * g.esize;
+    kvc::launch_gather(g, st);
+    return hip_ok("gather launch");
+}
+
+}  // namespace
+
+extern "C" {
+
+__attribute__((visibility("default"))) int kvc_version(void) { return KVC_VERSION; }
+
+__attribute__((visibility("default"))) const char* kvc_last_error(void) { return g_err; }
+
+__attribute__((visibility("default"))) size_t kvc_workspace_bytes(const kvc_params* p) {
+    if (validate(p, true) != KVC_OK) return 0;
+    g_err[0] = 0;
+    return carve(p).total;
+}
+
+__attribute__((visibility("default"))) int kvc_workspace_layout(const kvc_params* p, size_t offs[3]) {
+    if (int rc = validate(p, true)) return rc;
+    if (!offs) return fail(KVC_ERR_INVALID, "offs is NULL");
+    const Layout l = carve(p);
+    offs[0] = l.logits; offs[1] = l.rowmax; offs[2] = l.rowsum;
+    return KVC_OK;
+}
+
+__attribute__((visibility("default"))) int64_t kvc_pyramid_k(int64_t cap, int64_t W, int64_t q_len, int64_t layer_idx,
+                                                              int64_t n_layers, int64_t beta) {
+    // pyramidkv_utils.py:205-215 (Python floor division restated for possibly negative operands)
+    int64_t min_num = (cap - W) / beta;
+    if (((cap - W) % beta != 0) && (((cap - W) < 0) != (beta < 0))) --min_num;
+    int64_t max_num = (cap - W) * 2 - min_num;
+    if (max_num >= q_len - W) { max_num = q_len - W; min_num = (cap - W) * 2 - max_num; }
+    const int64_t num = max_num - min_num, den = n_layers - 1;
+    int64_t steps = 0;
+    if (den != 0) { steps = num / den; if ((num % den != 0) && ((num < 0) != (den < 0))) --steps; }
+    if (q_len < cap) return -1;                       // :218 pass-through
+    if (q_len < (cap - W) * 2) return cap - W;        // :220 SnapKV budget
+    return max_num - layer_idx * steps;               // :252
+}
+
+__attribute__((visibility("default"))) int kvc_scores(const kvc_params* p, const void* q, const void* k, void* scores_out,
+                                                      void* workspace, size_t workspace_bytes, void* hip_stream) {
+    if (int rc = validate(p, true)) return rc;
+    if (!scoring(p->method)) return fail(KVC_ERR_INVALID, "StreamingLLM has no scores");
+    if (!q || !k || !scores_out) return fail(KVC_ERR_INVALID, "q, k and scores_out must be non-NULL");
+    const int es = esize_of(p->dtype);
+    if (int rc = check_strides("q", es, p->q_stride_b, p->q_stride_h, p->q_stride_l, q)) return rc;
+    if (int rc = check_strides("k", es, p->k_stride_b, p->k_stride_h, p->k_stride_l, k)) return rc;
+    if (((uintptr_t)scores_out) % 16) return fail(KVC_ERR_ALIGNMENT, "scores_out not 16-byte aligned");
+    const Layout l = carve(p);
+    if (int rc = check_ws(l, workspace, workspace_bytes)) return rc;
+    return enqueue_scores(p, l, q, k, scores_out, static_cast<char*>(workspace), static_cast<hipStream_t>(hip_stream));
+}
+
+__attribute__((visibility("default"))) int kvc_select(const kvc_params* p, const void* scores, int64_t* idx_out,
+                                                      void* workspace, size_t workspace_bytes, void* hip_stream) {
+    (void)workspace; (void)workspace_bytes;
+    if (int rc = validate(p, false)) return rc;
+    if (!scores || !idx_out) return fail(KVC_ERR_INVALID, "scores and idx_out must be non-NULL");
+    if (((uintptr_t)scores) % 16 || ((uintptr_t)idx_out) % 16) return fail(KVC_ERR_ALIGNMENT, "scores / idx_out not 16-byte aligned");
+    return enqueue_select(p, scores, idx_out, static_cast<hipStream_t>(hip_stream));
+}
+
+__attribute__((visibility("default"))) int kvc_gather(const kvc_params* p, const void* src, int64_t stride_b, int64_t stride_h,
+                                                      int64_t stride_l, const int64_t* idx, void* out, void* hip_stream) {
+    if (int rc = validate(p, false)) return rc;
+    if (!src || !out) return fail(KVC_ERR_INVALID, "src and out must be non-NULL");
+    if (int rc = check_strides("src", esize_of(p->dtype), stride_b, stride_h, stride_l, src)) return rc;
+    if (((uintptr_t)out) % 16) return fail(KVC_ERR_ALIGNMENT, "out not 16-byte aligned");
+    return enqueue_gather(p, src, stride_b, stride_h, stride_l, idx, out, static_cast<hipStream_t>(hip_stream));
+}
+
+__attribute__((visibility("default"))) int kvc_compress(const kvc_params* p, const void* q, const void* k, const void* v,
+                                                        void* k_out, void* v_out, int64_t* idx_out, void* scores_out,
+                                                        void* workspace, size_t workspace_bytes, void* hip_stream) {
+    if (int rc = validate(p, true)) return rc;
+    if (!k || !v || !k_out || !v_out) return fail(KVC_ERR_INVALID, "k, v, k_out and v_out must be non-NULL");
+    const int es = esize_of(p->dtype);
+    if (int rc = check_strides("k", es, p->k_stride_b, p->k_stride_h, p->k_stride_l, k)) return rc;
+    if (int rc = check_strides("v", es, p->v_stride_b, p->v_stride_h, p->v_stride_l, v)) return rc;
+    if (((uintptr_t)k_out) % 16 || ((uintptr_t)v_out) % 16) return fail(KVC_ERR_ALIGNMENT, "k_out / v_out not 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const int64_t* idx = nullptr;
+    if (scoring(p->method)) {
+        if (!q) return fail(KVC_ERR_INVALID, "q must be non-NULL for scoring methods");
+        if (int rc = check_strides("q", es, p->q_stride_b, p->q_stride_h, p->q_stride_l, q)) return rc;
+        if (idx_out && ((uintptr_t)idx_out) % 16) return fail(KVC_ERR_ALIGNMENT, "idx_out not 16-byte aligned");
+        if (scores_out && ((uintptr_t)scores_out) % 16) return fail(KVC_ERR_ALIGNMENT, "scores_out not 16-byte aligned");
+        const Layout l = carve(p);
+        if (int rc = check_ws(l, workspace, workspace_bytes)) return rc;
+        char* ws = static_cast<char*>(workspace);
+        void* sc = scores_out ? scores_out : static_cast<void*>(ws + l.scores);
+        int64_t* ix = idx_out ? idx_out : reinterpret_cast<int64_t*>(ws + l.idx);
+        if (int rc = enqueue_scores(p, l, q, k, sc, ws, st)) return rc;
+        if (int rc = enqueue_select(p, sc, ix, st)) return rc;
+        idx = ix;
+    } else if (idx_out && p->k > 0) {
+        return fail(KVC_ERR_UNSUPPORTED, "StreamingLLM: idx_out must be NULL (indices are arange(k), pyramidkv_utils.py:607)");
+    }
+    if (int rc = enqueue_gather(p, k, p->k_stride_b, p->k_stride_h, p->k_stride_l, idx, k_out, st)) return rc;
+    return enqueue_gather(p, v, p->v_stride_b, p->v_stride_h, p->v_stride_l, idx, v_out, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,138 @@
+// kvc_common.h — device-side arithmetic shared by the gfx950 kernels.
+//
+// Every function here is the device twin of a host function in oracle/kvc_oracle.cpp and is built
+// from single IEEE-754 fp32 operations (add, mul, fma, floor, correctly rounded divide) so the two
+// agree bit for bit.  Compile with -ffp-contract=off: a contraction the source does not spell out
+// would change a rounding point.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/kvc.h"
+
+namespace kvc {
+
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+// ---- storage types -------------------------------------------------------------------------
+template <int DT> struct Dt;
+template <> struct Dt<KVC_BF16> {
+    typedef uint16_t raw;
+    static constexpr int esize = 2;
+    __device__ static __forceinline__ float ld(raw r) { return u2f((uint32_t)r << 16); }
+    __device__ static __forceinline__ raw st(float f) {   // RNE, NaN stays NaN
+        uint32_t u = f2u(f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (raw)((u >> 16) | 0x0040u);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (raw)(u >> 16);
+    }
+    __device__ static __forceinline__ float finfo_min() { return u2f(0xff7f0000u); }
+};
+template <> struct Dt<KVC_FP16> {
+    typedef uint16_t raw;
+    static constexpr int esize = 2;
+    __device__ static __forceinline__ float ld(raw r) {
+        _Float16 h;
+        __builtin_memcpy(&h, &r, 2);
+        return (float)h;
+    }
+    __device__ static __forceinline__ raw st(float f) {   // v_cvt_f16_f32: RNE, overflow -> inf
+        _Float16 h = (_Float16)f;
+        raw r;
+        __builtin_memcpy(&r, &h, 2);
+        return r;
+    }
+    __device__ static __forceinline__ float finfo_min() { return -65504.0f; }
+};
+template <> struct Dt<KVC_FP32> {
+    typedef float raw;
+    static constexpr int esize = 4;
+    __device__ static __forceinline__ float ld(raw r) { return r; }
+    __device__ static __forceinline__ raw st(float f) { return f; }
+    __device__ static __forceinline__ float finfo_min() { return u2f(0xff7fffffu); }
+};
+template <int DT> __device__ __forceinline__ float rnd(float f) { return Dt<DT>::ld(Dt<DT>::st(f)); }
+
+// ---- exp: the reference's softmax exponent (torch Vectorized<float>::exp_u20) ----------------
+__device__ __forceinline__ float exp_u20(float x) {
+    const float ln_flt_min = u2f(0xc2aeac50u), ln_flt_max = u2f(0x42b17218u);
+    const float log2ef = u2f(0x3fb8aa3bu), ln2f = u2f(0x3f317218u);
+    const float c1 = 0.999999701f, c2 = 0.499991506f, c3 = 0.166676521f, c4 = 0.0418978221f,
+                c5 = 0.00828929059f;
+    const bool below = x < ln_flt_min;
+    float s = (x < ln_flt_max) ? x : ln_flt_max;
+    s = (s > ln_flt_min) ? s : ln_flt_min;
+    float fx = __builtin_fmaf(s, log2ef, 0.5f);
+    fx = __builtin_floorf(fx);
+    const float r = __builtin_fmaf(-fx, ln2f, s);
+    float p = __builtin_fmaf(r, c5, c4);
+    p = __builtin_fmaf(r, p, c3);
+    p = __builtin_fmaf(r, p, c2);
+    p = __builtin_fmaf(r, p, c1);
+    p = __builtin_fmaf(r, p, 1.0f);
+    const int n1 = (int)(fx - 1.0f);
+    const float two_n = below ? 0.0f : u2f((uint32_t)(n1 + 127) << 23);
+    p = p * two_n;
+    p = p * 2.0f;
+    return p;
+}
+
+// ---- torch's cascade sum over the scored query rows (SumKernel.cpp multi_row_sum) -------------
+struct CascadeSum {
+    float a0, a1, a2, a3;
+    int i, in_step, level_step, level_power, full;
+    __device__ __forceinline__ void init(int size) {
+        int cl = 0;
+        while ((1 << cl) < size) ++cl;
+        level_power = cl / 4 > 4 ? cl / 4 : 4;
+        level_step = 1 << level_power;
+        full = size - (size % level_step);
+        a0 = a1 = a2 = a3 = 0.0f;
+        i = 0;
+        in_step = 0;
+    }
+    __device__ __forceinline__ void add(float v) {
+        a0 = a0 + v;
+        ++i;
+        ++in_step;
+        if (in_step == level_step && i <= full) {
+            in_step = 0;
+            const int mask = level_step - 1;
+            a1 = a1 + a0; a0 = 0.0f;
+            if ((i & (mask << level_power)) == 0) {
+                a2 = a2 + a1; a1 = 0.0f;
+                if ((i & (mask << (2 * level_power))) == 0) { a3 = a3 + a2; a2 = 0.0f; }
+            }
+        }
+    }
+    __device__ __forceinline__ float result() const { return ((a0 + a1) + a2) + a3; }
+};
+
+// ---- order-preserving integer keys for top-k (larger float -> larger key) ---------------------
+template <int DT> struct Key;
+template <> struct Key<KVC_BF16> {
+    static constexpr int bits = 16;
+    __device__ static __forceinline__ uint32_t of(uint16_t r) { return (r & 0x8000u) ? (uint32_t)(~r & 0xffffu) : (uint32_t)(r | 0x8000u); }
+};
+template <> struct Key<KVC_FP16> {
+    static constexpr int bits = 16;
+    __device__ static __forceinline__ uint32_t of(uint16_t r) { return (r & 0x8000u) ? (uint32_t)(~r & 0xffffu) : (uint32_t)(r | 0x8000u); }
+};
+template <> struct Key<KVC_FP32> {
+    static constexpr int bits = 32;
+    __device__ static __forceinline__ uint32_t of(float f) { uint32_t u = f2u(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+};
+
+__device__ __forceinline__ float wave_xor_sum(float v) {   // butterfly 1,2,4,8,16,32 (oracle: sum_kvc)
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) v = v + __shfl_xor(v, s);
+    return v;
+}
+__device__ __forceinline__ float half_xor_max(float v) {   // max over the 32 lanes sharing lane>>5
+#pragma unroll
+    for (int s = 1; s < 32; s <<= 1) { const float o = __shfl_xor(v, s); v = o > v ? o : v; }
+    return v;
+}
+
+}  // namespace kvc

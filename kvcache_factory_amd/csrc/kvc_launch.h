@@ -1,0 +1,41 @@
+// kvc_launch.h — argument blocks and host launch functions shared by the kernel files and kvc_api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kvc {
+
+struct ScoreArgs {
+    const void* q; const void* k;
+    void* logits;          // [bsz*Hq][L][W] dtype
+    float* pmax;           // [bsz*Hq][n_tiles][W]
+    float* psum;           // [bsz*Hq][n_chunks][W]
+    float* rowmax;         // [bsz*Hq][W]
+    float* rowsum;         // [bsz*Hq][W]
+    void* scores;          // [bsz*Hq][L-W] dtype
+    int64_t q_stride_b, q_stride_h, q_stride_l;
+    int64_t k_stride_b, k_stride_h, k_stride_l;
+    int bsz, n_q_heads, n_kv_heads, group, q_len, window;
+    int n_tiles, n_chunks, kernel_size, pooling;
+    float sqrt_d;
+};
+
+struct SelectArgs {
+    const void* scores;    // [bsz*Hq][n] dtype
+    int64_t* idx;          // [bsz*Hq][k]
+    int n, k, heads;       // heads = bsz*Hq
+    int pow2;              // next power of two >= k
+};
+
+struct GatherArgs {
+    const void* src; void* out; const int64_t* idx;   // idx may be null (identity)
+    int64_t stride_b, stride_h, stride_l;             // elements
+    int bsz, n_q_heads, group, q_len, window, k, row_bytes, esize;
+};
+
+int launch_scores(const ScoreArgs& a, int dtype, int head_dim, hipStream_t st);
+int launch_select(const SelectArgs& a, int dtype, int tie_mode, hipStream_t st);
+size_t select_lds_bytes(int k);
+int launch_gather(const GatherArgs& a, hipStream_t st);
+
+}  // namespace kvc

@@ -1,0 +1,353 @@
+// kvc_score.hip — A1..A5 of the reference hot path on gfx950 (MI355X):
+//   window QK^T (+ scale, + local causal mask)   pyramidkv_utils.py:317-324
+//   fp32 softmax over all L keys, cast to dtype  :326
+//   sum over the W window rows                    :327
+//   1-D max / avg pooling                         :328-333
+//
+// Three kernels, one HBM pass over K:
+//   logits_kernel  : one workgroup = 128 keys of one KV head; the K tile is staged once in LDS
+//                    (coalesced 16-B loads, XOR-swizzled rows) and contracted against the G*W query
+//                    rows of the KV head's query group with the f32-input MFMA
+//                    v_mfma_f32_32x32x2_f32, whose result is bit for bit the d-ascending fmaf chain
+//                    the oracle computes (KVCO_DOT_CHAIN).  Epilogue applies the reference's three
+//                    roundings, writes logits [h][L][W] and the tile's per-row maximum.
+//   rowsum_kernel  : one workgroup = 256 keys of one query head: row max from the tile maxima,
+//                    e = exp_u20(x - max), fixed-order partial sums (oracle: sum_kvc).
+//   pool_kernel    : one workgroup = 256 candidate keys (+ pooling halo): p = round(e / sum),
+//                    window sum in torch's cascade order, round, pool, write the scores.
+#include "kvc_common.h"
+#include "kvc_launch.h"
+
+namespace kvc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Pull the element with parity `kh` of bf16/fp16 pair s out of a 16-byte chunk (8 elements),
+// or of fp32 pair s out of a 16-byte chunk (4 elements).
+template <int DT> __device__ __forceinline__ float pick(const uint4& v, int s, int kh);
+template <> __device__ __forceinline__ float pick<KVC_BF16>(const uint4& v, int s, int kh) {
+    const uint32_t w = s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w;
+    return u2f(kh ? (w & 0xffff0000u) : (w << 16));
+}
+template <> __device__ __forceinline__ float pick<KVC_FP16>(const uint4& v, int s, int kh) {
+    const uint32_t w = s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w;
+    return Dt<KVC_FP16>::ld((uint16_t)(kh ? (w >> 16) : (w & 0xffffu)));
+}
+template <> __device__ __forceinline__ float pick<KVC_FP32>(const uint4& v, int s, int kh) {
+    // chunk holds d = 4c..4c+3; pair s in {0,1} -> elements 2s, 2s+1
+    const uint32_t w = s == 0 ? (kh ? v.y : v.x) : (kh ? v.w : v.z);
+    return u2f(w);
+}
+
+// ---------------------------------------------------------------------------------------------
+// logits_kernel
+// grid  = (ceil(L/128), bsz * n_kv_heads), block = 256 (4 waves x 32 keys)
+// LDS   = 128 * D * esize (K tile) + 4*32*4 (per-wave row maxima)
+// ---------------------------------------------------------------------------------------------
+template <int DT, int D>
+__global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
+    typedef typename Dt<DT>::raw raw;
+    constexpr int ES = Dt<DT>::esize;
+    constexpr int ROWB = D * ES;             // bytes per key row
+    constexpr int CH = ROWB / 16;            // 16-byte chunks per row
+    constexpr int PAIRS = 8 / ES;            // mfma k-pairs per chunk: 4 (16-bit) or 2 (fp32)
+    constexpr int SWZ = CH < 16 ? CH - 1 : 15;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* wmax = reinterpret_cast<float*>(smem + 128 * ROWB);   // [4][32]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+    const int tile = blockIdx.x;
+    const int b = blockIdx.y / a.n_kv_heads, g = blockIdx.y % a.n_kv_heads;
+    const int L = a.q_len, W = a.window, G = a.group;
+    const int key0 = tile * 128;
+
+    // ---- stage the K tile: 128 rows x CH chunks, coalesced, swizzled ----
+    const char* kbase = reinterpret_cast<const char*>(a.k) +
+                        ((int64_t)b * a.k_stride_b + (int64_t)g * a.k_stride_h) * ES;
+    for (int c = tid; c < 128 * CH; c += 256) {
+        const int r = c / CH, cc = c % CH;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (key0 + r < L)
+            v = *reinterpret_cast<const uint4*>(kbase + (int64_t)(key0 + r) * a.k_stride_l * ES + cc * 16);
+        *reinterpret_cast<uint4*>(smem + r * ROWB + ((cc ^ (r & SWZ)) * 16)) = v;
+    }
+    __syncthreads();
+
+    const int rows = G * W;                   // query rows sharing this KV head
+    const int n_mt = (rows + 31) / 32;
+    const int key = key0 + wave * 32 + j;
+    const float sqrt_d = a.sqrt_d;
+    const char* krow = smem + (wave * 32 + j) * ROWB;
+
+    for (int mt = 0; mt < n_mt; ++mt) {
+        // ---- A operand: this lane's query row, its parity's elements, as fp32 ----
+        float areg[D / 2];
+        {
+            const int i = mt * 32 + j;
+            const bool valid = i < rows;
+            const int hq = g * G + (valid ? i / W : 0), w = valid ? i % W : 0;
+            const char* qrow = reinterpret_cast<const char*>(a.q) +
+                ((int64_t)b * a.q_stride_b + (int64_t)hq * a.q_stride_h + (int64_t)(L - W + w) * a.q_stride_l) * ES;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (valid) v = *reinterpret_cast<const uint4*>(qrow + c * 16);
+#pragma unroll
+                for (int s = 0; s < PAIRS; ++s) areg[c * PAIRS + s] = pick<DT>(v, s, kh);
+            }
+        }
+        // ---- 32 rows x 32 keys, chain over d = 0..D-1 in order ----
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const uint4 kv = *reinterpret_cast<const uint4*>(krow + ((c ^ (j & SWZ)) * 16));
+#pragma unroll
+            for (int s = 0; s < PAIRS; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c * PAIRS + s], pick<DT>(kv, s, kh), acc, 0, 0, 0);
+        }
+        // ---- epilogue: 3 roundings, mask, store [h][key][w], tile row maxima ----
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            float x[4];
+            const int i0 = mt * 32 + 8 * rg + 4 * kh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + e;
+                const int w = i % W;
+                float v = rnd<DT>(acc[rg * 4 + e]);
+                v = rnd<DT>(v / sqrt_d);
+                if (key >= L - W && (key - (L - W)) > w) v = rnd<DT>(v + Dt<DT>::finfo_min());
+                x[e] = v;
+            }
+            const bool vec_ok = (W % 4) == 0;
+            if (i0 < rows && key < L) {
+                if (vec_ok) {
+                    const int hq = g * G + i0 / W, w0 = i0 % W;
+                    raw* dst = reinterpret_cast<raw*>(a.logits) + (((int64_t)b * a.n_q_heads + hq) * L + key) * W + w0;
+                    if constexpr (ES == 2) {
+                        uint2 pk;
+                        pk.x = (uint32_t)Dt<DT>::st(x[0]) | ((uint32_t)Dt<DT>::st(x[1]) << 16);
+                        pk.y = (uint32_t)Dt<DT>::st(x[2]) | ((uint32_t)Dt<DT>::st(x[3]) << 16);
+                        *reinterpret_cast<uint2*>(dst) = pk;
+                    } else {
+                        *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = i0 + e;
+                        if (i < rows) {
+                            const int hq = g * G + i / W, w = i % W;
+                            reinterpret_cast<raw*>(a.logits)[(((int64_t)b * a.n_q_heads + hq) * L + key) * W + w] = Dt<DT>::st(x[e]);
+                        }
+                    }
+                }
+            }
+            // per-row maximum over this wave's 32 keys
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float m = (key < L) ? x[e] : -__builtin_inff();
+                m = half_xor_max(m);
+                if (j == 0) wmax[wave * 32 + 8 * rg + 4 * kh + e] = m;
+            }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int i = mt * 32 + tid;
+            if (i < rows) {
+                float m = wmax[tid];
+#pragma unroll
+                for (int wv = 1; wv < 4; ++wv) { const float o = wmax[wv * 32 + tid]; m = o > m ? o : m; }
+                const int hq = g * G + i / W, w = i % W;
+                a.pmax[(((int64_t)b * a.n_q_heads + hq) * a.n_tiles + tile) * W + w] = m;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row maxima of one head from the tile maxima: result in LDS m[0..W).  256 threads.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_row_max(const float* pmax /*[n_tiles][W]*/, int n_tiles, int W,
+                                               float* m /*LDS [W]*/, float* scratch /*LDS [256]*/) {
+    const int tid = threadIdx.x;
+    int Wp = 1;
+    while (Wp < W) Wp <<= 1;               // W <= 64
+    const int parts = 256 / Wp, w = tid % Wp, part = tid / Wp;
+    float v = -__builtin_inff();
+    if (w < W)
+        for (int t = part; t < n_tiles; t += parts) { const float o = pmax[(int64_t)t * W + w]; v = o > v ? o : v; }
+    scratch[tid] = v;
+    __syncthreads();
+    if (tid < W) {
+        float r = scratch[tid];
+        for (int p = 1; p < parts; ++p) { const float o = scratch[p * Wp + tid]; r = o > r ? o : r; }
+        m[tid] = r;
+    }
+    __syncthreads();
+}
+
+// Load the W logits of one key (contiguous W*ES bytes) widened to fp32.  WV > 0: W is the
+// compile-time constant WV (multiple of 8) and x[] stays in registers; WV == 0: runtime W <= 64.
+template <int DT, int WV>
+__device__ __forceinline__ void load_logits(const typename Dt<DT>::raw* src, int W, float* x /*[WV or 64]*/) {
+    constexpr int ES = Dt<DT>::esize;
+    constexpr int PER16 = 16 / ES;
+    if (WV > 0 || (W % PER16) == 0) {
+#pragma unroll
+        for (int c = 0; c < (WV > 0 ? WV : W) / PER16; ++c) {
+            const uint4 v = reinterpret_cast<const uint4*>(src)[c];
+            const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (ES == 2) {
+                    x[c * 8 + 2 * e] = Dt<DT>::ld((uint16_t)(wd[e] & 0xffffu));
+                    x[c * 8 + 2 * e + 1] = Dt<DT>::ld((uint16_t)(wd[e] >> 16));
+                } else {
+                    x[c * 4 + e] = u2f(wd[e]);
+                }
+            }
+        }
+    } else {
+        for (int w = 0; w < W; ++w) x[w] = Dt<DT>::ld(src[w]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rowsum_kernel: grid = (ceil(L/256), bsz*n_q_heads), block = 256, one key per thread.
+// psum[hb][chunk][w] = fixed-order sum over the chunk's keys of exp_u20(x[key][w] - max[w]).
+// ---------------------------------------------------------------------------------------------
+template <int DT, int WV>
+__global__ __launch_bounds__(256) void rowsum_kernel(const ScoreArgs a) {
+    typedef typename Dt<DT>::raw raw;
+    __shared__ float m[64];
+    __shared__ float scratch[256];
+    __shared__ float wsum[4 * 64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int chunk = blockIdx.x, hb = blockIdx.y;
+    const int L = a.q_len, W = WV > 0 ? WV : a.window;
+    block_row_max(a.pmax + (int64_t)hb * a.n_tiles * W, a.n_tiles, W, m, scratch);
+    if (chunk == 0 && tid < W) a.rowmax[(int64_t)hb * W + tid] = m[tid];
+
+    const int key = chunk * 256 + tid;
+    float x[WV > 0 ? WV : 64];
+    if (key < L) load_logits<DT, WV>(reinterpret_cast<const raw*>(a.logits) + ((int64_t)hb * L + key) * W, W, x);
+#pragma unroll
+    for (int w = 0; w < (WV > 0 ? WV : W); ++w) {
+        float e = (key < L) ? exp_u20(x[w] - m[w]) : 0.0f;
+        e = wave_xor_sum(e);
+        if (lane == 0) wsum[wave * 64 + w] = e;
+    }
+    __syncthreads();
+    if (tid < W) {
+        const float s = ((wsum[tid] + wsum[64 + tid]) + wsum[128 + tid]) + wsum[192 + tid];
+        a.psum[((int64_t)hb * a.n_chunks + chunk) * W + tid] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pool_kernel: grid = (ceil(n/256), bsz*n_q_heads), block = 256.
+// ---------------------------------------------------------------------------------------------
+template <int DT, int WV>
+__global__ __launch_bounds__(256) void pool_kernel(const ScoreArgs a) {
+    typedef typename Dt<DT>::raw raw;
+    __shared__ float m[64];
+    __shared__ float rinv[64];
+    __shared__ float s_tile[256 + 64];
+    const int tid = threadIdx.x;
+    const int hb = blockIdx.y;
+    const int L = a.q_len, W = WV > 0 ? WV : a.window, n = L - W;
+    const int pad = a.pooling == KVC_POOL_NONE ? 0 : a.kernel_size / 2;
+    const int j0 = blockIdx.x * 256;
+
+    if (tid < W) {
+        m[tid] = a.rowmax[(int64_t)hb * W + tid];
+        float s = 0.0f;
+        for (int c = 0; c < a.n_chunks; ++c) {
+            const float v = a.psum[((int64_t)hb * a.n_chunks + c) * W + tid];
+            s = c == 0 ? v : s + v;
+        }
+        rinv[tid] = 1.0f / s;
+        if (blockIdx.x == 0) a.rowsum[(int64_t)hb * W + tid] = s;
+    }
+    __syncthreads();
+
+    for (int t = tid; t < 256 + 2 * pad; t += 256) {
+        const int key = j0 - pad + t;
+        float sv = 0.0f;
+        if (key >= 0 && key < n) {
+            float x[WV > 0 ? WV : 64];
+            load_logits<DT, WV>(reinterpret_cast<const raw*>(a.logits) + ((int64_t)hb * L + key) * W, W, x);
+            CascadeSum cs;
+            cs.init(W);
+#pragma unroll
+            for (int w = 0; w < (WV > 0 ? WV : W); ++w) {
+                const float e = exp_u20(x[w] - m[w]);
+                cs.add(rnd<DT>(e * rinv[w]));
+            }
+            sv = rnd<DT>(cs.result());
+        }
+        s_tile[t] = sv;
+    }
+    __syncthreads();
+
+    const int jo = j0 + tid;
+    if (jo < n) {
+        float c;
+        if (a.pooling == KVC_POOL_NONE) {
+            c = s_tile[tid];
+        } else {
+            const int lo = jo - pad < 0 ? 0 : jo - pad;
+            const int hi = jo - pad + a.kernel_size > n ? n : jo - pad + a.kernel_size;
+            if (a.pooling == KVC_POOL_MAX) {
+                c = -__builtin_inff();
+                for (int i = lo; i < hi; ++i) { const float v = s_tile[i - j0 + pad]; c = v > c ? v : c; }
+            } else {
+                float acc = 0.0f;
+                for (int i = lo; i < hi; ++i) acc = acc + s_tile[i - j0 + pad];
+                c = rnd<DT>(acc / (float)a.kernel_size);
+            }
+        }
+        reinterpret_cast<raw*>(a.scores)[(int64_t)hb * n + jo] = Dt<DT>::st(c);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launch
+// ---------------------------------------------------------------------------------------------
+template <int DT, int WV>
+static void launch_softmax_pool_t(const ScoreArgs& a, hipStream_t st) {
+    dim3 g2((unsigned)a.n_chunks, (unsigned)(a.bsz * a.n_q_heads));
+    hipLaunchKernelGGL((rowsum_kernel<DT, WV>), g2, dim3(256), 0, st, a);
+    const int n = a.q_len - a.window;
+    dim3 g3((unsigned)((n + 255) / 256), (unsigned)(a.bsz * a.n_q_heads));
+    hipLaunchKernelGGL((pool_kernel<DT, WV>), g3, dim3(256), 0, st, a);
+}
+
+template <int DT, int D>
+static int launch_scores_t(const ScoreArgs& a, hipStream_t st) {
+    constexpr int ES = Dt<DT>::esize;
+    const size_t lds = (size_t)128 * D * ES + 4 * 32 * sizeof(float);
+    dim3 g1((unsigned)a.n_tiles, (unsigned)(a.bsz * a.n_kv_heads));
+    hipLaunchKernelGGL((logits_kernel<DT, D>), g1, dim3(256), lds, st, a);
+    switch (a.window) {
+        case 8:  launch_softmax_pool_t<DT, 8>(a, st); break;
+        case 16: launch_softmax_pool_t<DT, 16>(a, st); break;
+        case 32: launch_softmax_pool_t<DT, 32>(a, st); break;
+        case 64: launch_softmax_pool_t<DT, 64>(a, st); break;
+        default: launch_softmax_pool_t<DT, 0>(a, st); break;
+    }
+    return 0;
+}
+
+int launch_scores(const ScoreArgs& a, int dtype, int head_dim, hipStream_t st) {
+#define KVC_CASE(DT_, D_) if (dtype == DT_ && head_dim == D_) return launch_scores_t<DT_, D_>(a, st)
+    KVC_CASE(KVC_BF16, 128); KVC_CASE(KVC_BF16, 64);
+    KVC_CASE(KVC_FP16, 128); KVC_CASE(KVC_FP16, 64);
+    KVC_CASE(KVC_FP32, 128); KVC_CASE(KVC_FP32, 64);
+#undef KVC_CASE
+    return KVC_ERR_UNSUPPORTED;
+}
+
+}  // namespace kvc

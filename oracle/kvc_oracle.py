@@ -1,0 +1,181 @@
+"""ctypes binding of oracle/libkvc_oracle.so — the CPU restatement of the reference hot path.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg, never by the product package (kvcache_factory_amd/).  See kvc_oracle.cpp for the reference
+file:line each function restates (pyramidkv/pyramidkv_utils.py:197-283, :306-347, :533-575, :595-620).
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libkvc_oracle.so")
+
+BF16, FP16, FP32 = 0, 1, 2
+POOL_NONE, POOL_AVG, POOL_MAX = 0, 1, 2
+DOT_CHAIN, DOT_F64 = 0, 1
+SUM_TORCH16, SUM_KVC = 0, 1
+TIES_TORCH, TIES_CANON = 0, 1
+
+_DTYPE = {torch.bfloat16: BF16, torch.float16: FP16, torch.float32: FP32}
+_POOL = {None: POOL_NONE, "none": POOL_NONE, "avgpool": POOL_AVG, "maxpool": POOL_MAX}
+
+
+class Params(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "dtype", "n_q_heads", "n_kv_heads", "q_len", "head_dim", "window", "k", "kernel_size",
+        "pooling", "full_rows", "dot_mode", "sum_mode", "tie_mode", "n_threads")] + [
+        (n, ctypes.c_int64) for n in (
+            "q_stride_h", "q_stride_l", "k_stride_h", "k_stride_l", "v_stride_h", "v_stride_l")]
+
+
+def build(force=False):
+    """Compile the oracle with g++ (oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH) or (
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "kvc_oracle.cpp"))):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libkvc_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        vp, i64p = ctypes.c_void_p, ctypes.c_void_p
+        pp = ctypes.POINTER(Params)
+        L.kvco_version.restype = ctypes.c_int
+        L.kvco_scores.argtypes = [pp, vp, vp, vp, vp, vp, vp]
+        L.kvco_topk.argtypes = [pp, vp, i64p, vp]
+        L.kvco_gather.argtypes = [pp, vp, ctypes.c_int64, ctypes.c_int64, i64p, vp]
+        L.kvco_compress.argtypes = [pp, vp, vp, vp, vp, vp, i64p, vp]
+        L.kvco_streaming.argtypes = [pp, vp, vp, vp, vp, i64p]
+        L.kvco_pyramid_k.argtypes = [ctypes.c_int64] * 6
+        L.kvco_pyramid_k.restype = ctypes.c_int64
+        L.kvco_exp_u20.argtypes = [ctypes.c_float]
+        L.kvco_exp_u20.restype = ctypes.c_float
+        L.kvco_sum.argtypes = [vp, ctypes.c_int64, ctypes.c_int]
+        L.kvco_sum.restype = ctypes.c_float
+        L.kvco_f32_to_f16.argtypes = [ctypes.c_float]
+        L.kvco_f32_to_f16.restype = ctypes.c_uint16
+        L.kvco_f16_to_f32.argtypes = [ctypes.c_uint16]
+        L.kvco_f16_to_f32.restype = ctypes.c_float
+        L.kvco_f32_to_bf16.argtypes = [ctypes.c_float]
+        L.kvco_f32_to_bf16.restype = ctypes.c_uint16
+        _lib = L
+    return _lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _check_inner(t):
+    assert t.device.type == "cpu" and t.stride(-1) == 1, "oracle wants CPU tensors, last dim contiguous"
+
+
+def make_params(q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", full_rows=False,
+                dot_mode=DOT_CHAIN, sum_mode=SUM_KVC, tie_mode=TIES_TORCH, n_threads=0):
+    """q: [1,Hq,L,D] (any h/l strides); k,v: [1,Hq or Hkv,L,D]."""
+    assert q.dim() == 4 and q.shape[0] == 1, "bsz must be 1 (reference README.md:29)"
+    _check_inner(q), _check_inner(k)
+    p = Params()
+    p.dtype = _DTYPE[q.dtype]
+    p.n_q_heads, p.n_kv_heads = q.shape[1], k.shape[1]
+    p.q_len, p.head_dim = q.shape[2], q.shape[3]
+    p.window, p.k = window, n_keep
+    p.kernel_size, p.pooling, p.full_rows = kernel_size, _POOL[pooling], int(full_rows)
+    p.dot_mode, p.sum_mode, p.tie_mode, p.n_threads = dot_mode, sum_mode, tie_mode, n_threads
+    p.q_stride_h, p.q_stride_l = q.stride(1), q.stride(2)
+    p.k_stride_h, p.k_stride_l = k.stride(1), k.stride(2)
+    if v is not None:
+        _check_inner(v)
+        p.v_stride_h, p.v_stride_l = v.stride(1), v.stride(2)
+    return p
+
+
+def _rc(code, what):
+    if code != 0:
+        raise RuntimeError(f"oracle {what} failed with code {code}")
+
+
+def scores(q, k, window, kernel_size=5, pooling="avgpool", full_rows=False, want_intermediates=False, **modes):
+    """A1-A5 (A10 with full_rows).  Returns pooled scores [Hq, n] (+ logits, probs, wsum)."""
+    p = make_params(q, k, None, window, 0, kernel_size, pooling, full_rows, **modes)
+    H, L = q.shape[1], q.shape[2]
+    n, R = L - window, (L if full_rows else window)
+    out = torch.empty(H, n, dtype=q.dtype)
+    lg = pr = ws = None
+    if want_intermediates:
+        lg, pr = torch.empty(H, R, L, dtype=q.dtype), torch.empty(H, R, L, dtype=q.dtype)
+        ws = torch.empty(H, n, dtype=q.dtype)
+    _rc(lib().kvco_scores(ctypes.byref(p), _ptr(q), _ptr(k), _ptr(lg), _ptr(pr), _ptr(ws), _ptr(out)), "scores")
+    return (out, lg, pr, ws) if want_intermediates else out
+
+
+def topk(scores_t, n_keep, tie_mode=TIES_TORCH, n_threads=0):
+    """A7 on pooled scores [H, n] -> (indices int64 [H,k], values [H,k])."""
+    assert scores_t.dim() == 2 and scores_t.is_contiguous()
+    p = Params()
+    p.dtype = _DTYPE[scores_t.dtype]
+    p.n_q_heads = p.n_kv_heads = scores_t.shape[0]
+    p.window, p.head_dim = 1, 1
+    p.q_len = scores_t.shape[1] + 1
+    p.k, p.pooling, p.tie_mode, p.n_threads = n_keep, POOL_NONE, tie_mode, n_threads
+    idx = torch.empty(scores_t.shape[0], n_keep, dtype=torch.int64)
+    val = torch.empty(scores_t.shape[0], n_keep, dtype=scores_t.dtype)
+    _rc(lib().kvco_topk(ctypes.byref(p), _ptr(scores_t), _ptr(idx), _ptr(val)), "topk")
+    return idx, val
+
+
+def gather(src, idx, window, n_q_heads):
+    """A8 for one tensor: src [1,Hs,L,D], idx [Hq,k] -> [1,Hq,k+W,D]."""
+    _check_inner(src)
+    k = idx.shape[1]
+    p = Params()
+    p.dtype = _DTYPE[src.dtype]
+    p.n_q_heads, p.n_kv_heads = n_q_heads, src.shape[1]
+    p.q_len, p.head_dim, p.window, p.k, p.pooling = src.shape[2], src.shape[3], window, k, POOL_NONE
+    out = torch.empty(1, n_q_heads, k + window, src.shape[3], dtype=src.dtype)
+    _rc(lib().kvco_gather(ctypes.byref(p), _ptr(src), src.stride(1), src.stride(2), _ptr(idx.contiguous()),
+                          _ptr(out)), "gather")
+    return out
+
+
+def compress(q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", full_rows=False, **modes):
+    """A0/A9/A10 end to end.  Returns (k_out, v_out, idx, pooled_scores)."""
+    p = make_params(q, k, v, window, n_keep, kernel_size, pooling, full_rows, **modes)
+    H, L, D = q.shape[1], q.shape[2], q.shape[3]
+    k_out = torch.empty(1, H, n_keep + window, D, dtype=k.dtype)
+    v_out = torch.empty_like(k_out)
+    idx = torch.empty(H, n_keep, dtype=torch.int64)
+    sc = torch.empty(H, L - window, dtype=q.dtype)
+    _rc(lib().kvco_compress(ctypes.byref(p), _ptr(q), _ptr(k), _ptr(v), _ptr(k_out), _ptr(v_out), _ptr(idx),
+                            _ptr(sc)), "compress")
+    return k_out, v_out, idx, sc
+
+
+def streaming(k, v, window, n_keep, n_q_heads):
+    """A11 StreamingLLM: first n_keep + last W tokens."""
+    _check_inner(k), _check_inner(v)
+    p = Params()
+    p.dtype = _DTYPE[k.dtype]
+    p.n_q_heads, p.n_kv_heads = n_q_heads, k.shape[1]
+    p.q_len, p.head_dim, p.window, p.k, p.pooling = k.shape[2], k.shape[3], window, n_keep, POOL_NONE
+    p.k_stride_h, p.k_stride_l, p.v_stride_h, p.v_stride_l = k.stride(1), k.stride(2), v.stride(1), v.stride(2)
+    k_out = torch.empty(1, n_q_heads, n_keep + window, k.shape[3], dtype=k.dtype)
+    v_out = torch.empty_like(k_out)
+    idx = torch.empty(n_q_heads, n_keep, dtype=torch.int64)
+    _rc(lib().kvco_streaming(ctypes.byref(p), _ptr(k), _ptr(v), _ptr(k_out), _ptr(v_out), _ptr(idx)), "streaming")
+    return k_out, v_out, idx
+
+
+def pyramid_k(cap, window, q_len, layer_idx, n_layers, beta=20):
+    """A9 schedule (pyramidkv_utils.py:205-215): k for this layer, or -1 for pass-through."""
+    return int(lib().kvco_pyramid_k(cap, window, q_len, layer_idx, n_layers, beta))
