@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py — KV tokens compressed/sec for the post-prefill scoring+eviction hot path on MI355X.
+
+Metric (BASELINE.json): "KV tokens compressed/sec + selection-index exact-match, Llama-3-8B 8k->128".
+One "step" = the compression of ONE 8k-token prompt = 32 `update_kv` calls (one per layer of Llama-3-8B, each on
+that layer's own synthetic Q/K/V, already resident in HBM), enqueued back to back through the C-ABI
+(kvc_compress) exactly as the patched attention forward does.  tokens/step = q_len * 32 layers.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2_w32|c4|c5] [--tie-mode canonical|torch_cpu]
+
+N > 1 (torchrun, one rank per GPU): the path shards by independent prompts/layers with no exchange, so every rank
+runs its own replica of the workload (weak scaling); time = max over ranks, value = N * tokens / time.
+Prints ONE JSON line (rank 0).  See DESIGN.md §Measurement for the byte accounting.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from kvcache_factory_amd import _kvc, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured float4-copy rate
+
+CONFIGS = {
+    # name: (method, q_len, cap, window, kernel, pooling, dtype, per-layer-k?)
+    "c2": dict(method="snapkv", L=8000, cap=128, W=8, kernel=7, pooling="maxpool", dtype=torch.bfloat16,
+               desc="SnapKV Llama-3-8B shapes (Hq=32,Hkv=8,D=128), seq_len=8000 -> max_capacity_prompt=128, bf16, W=8, maxpool7"),
+    "c2_w32": dict(method="snapkv", L=8000, cap=128, W=32, kernel=7, pooling="maxpool", dtype=torch.bfloat16,
+                   desc="SnapKV 8k->128, W=32 (needle-runner window)"),
+    "c4": dict(method="pyramidkv", L=8000, cap=128, W=8, kernel=7, pooling="maxpool", dtype=torch.bfloat16,
+               desc="PyramidKV 8k, total budget 128x32 (k_l = 234..17)"),
+    "c5": dict(method="pyramidkv", L=32000, cap=2048, W=8, kernel=7, pooling="maxpool", dtype=torch.bfloat16,
+               desc="PyramidKV Mistral-7B shapes, 32k -> 2048 (k_l = 3978..103)"),
+}
+HQ, HKV, D, LAYERS = 32, 8, 128, 32
+METHODS = {"snapkv": _kvc.SNAPKV, "pyramidkv": _kvc.PYRAMIDKV}
+
+
+def algorithmic_bytes(L, W, k, es=2):
+    """GQA-aware bytes one layer call must move (K scan once, V never scanned)."""
+    scan = HKV * L * D * es + HQ * W * D * es                       # K scan + Q window  (the K-scan kernel's share)
+    compact = 2 * HQ * k * D * es + 2 * HKV * W * D * es + 2 * HQ * (k + W) * D * es + 8 * HQ * k
+    return scan, scan + compact
+
+
+def layer_budgets(cfg):
+    if cfg["method"] == "pyramidkv":
+        return [_kvc.pyramid_k(cfg["cap"], cfg["W"], cfg["L"], l, LAYERS) for l in range(LAYERS)]
+    return [cfg["cap"] - cfg["W"]] * LAYERS
+
+
+def build_plans(cfg, dev, tie_mode, expanded, seed0=0):
+    plans = []
+    ks = layer_budgets(cfg)
+    for l in range(LAYERS):
+        q, k, v = synth.make_qkv(HQ, HKV, cfg["L"], D, cfg["dtype"], seed0 + l, expanded=expanded, device=dev)
+        if expanded:
+            k, v = k.contiguous(), v.contiguous()
+        plans.append(_kvc.CompressPlan(METHODS[cfg["method"]], q, k, v, cfg["W"], ks[l], cfg["kernel"], cfg["pooling"],
+                                       tie_mode, want_indices=True))
+    return plans, ks
+
+
+def run_step(plans, stream):
+    for p in plans:
+        p.run(stream)
+
+
+def time_steps(plans, steps, warmup, dev, dist):
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for _ in range(warmup):
+        run_step(plans, stream)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run_step(plans, stream)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def time_scan_kernel(plans, dev, reps=20):
+    """Average duration of ONE launch of the dominant kernel (the K-scan / window-logits kernel), measured live with
+    HIP events on the launch stream: kvc_scores with debug_stage_mask=1 enqueues only that kernel."""
+    lib = _kvc.lib()
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    calls = []
+    for p in plans:
+        pp = _kvc.Params.from_buffer_copy(p.p)
+        pp.debug_stage_mask = 1
+        sc = torch.empty(1, HQ, p.k.shape[2] - p.p.window, dtype=p.k.dtype, device=dev)
+        calls.append((pp, p, sc))
+
+    def sweep():
+        for pp, p, sc in calls:
+            rc = lib.kvc_scores(ctypes.byref(pp), _kvc._ptr(p.q), _kvc._ptr(p.k), _kvc._ptr(sc), _kvc._ptr(p.ws), p.nbytes, stream)
+            assert rc == 0, lib.kvc_last_error()
+    sweep()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        sweep()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) * 1e-3 / (reps * len(calls))
+
+
+def cpu_baseline(cfg, budget_s=12.0):
+    """The CPU oracle (a port of the reference's algorithm, oracle/kvc_oracle.cpp) timed on this host's cores on a
+    bounded sample of the same workload: whole layer calls of the bench config, repeated for ~budget_s seconds."""
+    from oracle import kvc_oracle as O      # cpu_baseline leg only (the checker, timed as the baseline)
+    threads = os.cpu_count() or 1
+    L = cfg["L"]
+    q, k, v = synth.make_qkv(HQ, HKV, L, D, cfg["dtype"], 0)
+    n_keep = layer_budgets(cfg)[0]
+    O.compress(q, k, v, cfg["W"], n_keep, cfg["kernel"], cfg["pooling"], n_threads=threads)     # warm-up
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:
+        O.compress(q, k, v, cfg["W"], n_keep, cfg["kernel"], cfg["pooling"], n_threads=threads)
+        n += 1
+    dt = time.perf_counter() - t0
+    out = {"value": n * L / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
+           "sample": f"{n} layer calls of the bench config (L={L}, k={n_keep}, all {HQ} heads), oracle/kvc_oracle.cpp, OpenMP over heads"}
+    # the stock torch-CPU op sequence the reference executes (pyramidkv_utils.py:317-346), same inputs, same host
+    try:
+        import math
+        import torch.nn.functional as F
+        torch.set_num_threads(threads)
+        kx, vx = k.repeat_interleave(HQ // HKV, 1), v.repeat_interleave(HQ // HKV, 1)
+        W = cfg["W"]
+
+        def ref_ops():
+            aw = torch.matmul(q[..., -W:, :], kx.transpose(2, 3)) / math.sqrt(D)
+            mask = torch.full((W, W), torch.finfo(aw.dtype).min)
+            mc = torch.arange(W)
+            mask.masked_fill_(mc < (mc + 1).view(W, 1), 0)
+            aw[:, :, -W:, -W:] += mask[None, None]
+            aw = F.softmax(aw, dim=-1, dtype=torch.float32).to(q.dtype)
+            s = aw[:, :, -W:, :-W].sum(dim=-2)
+            c = (F.max_pool1d if cfg["pooling"] == "maxpool" else F.avg_pool1d)(s, kernel_size=cfg["kernel"], padding=cfg["kernel"] // 2, stride=1)
+            idx = c.topk(n_keep, dim=-1).indices.unsqueeze(-1).expand(-1, -1, -1, D)
+            return (torch.cat([kx[:, :, :-W].gather(2, idx), kx[:, :, -W:]], 2), torch.cat([vx[:, :, :-W].gather(2, idx), vx[:, :, -W:]], 2))
+        for _ in range(3):
+            ref_ops()
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < min(budget_s, 6.0):
+            ref_ops()
+            n += 1
+        out["torch_cpu_ops_tokens_per_s"] = n * L / (time.perf_counter() - t0)
+        out["torch_cpu_ops_threads"] = threads
+    except Exception as e:  # pragma: no cover
+        out["torch_cpu_ops_error"] = repr(e)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--tie-mode", default="canonical", choices=["canonical", "torch_cpu"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (expanded K/V, exact ties)")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    cfg = CONFIGS[a.config]
+
+    plans, ks = build_plans(cfg, dev, a.tie_mode, expanded=False)
+    dt = time_steps(plans, a.steps, a.warmup, dev, dist)
+    tokens_per_step = cfg["L"] * LAYERS
+    value = world * a.steps * tokens_per_step / dt
+
+    out = {
+        "metric": "KV tokens compressed/sec", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": cfg["desc"], "name": a.config, "layers_per_step": LAYERS, "q_len": cfg["L"], "budget": cfg["cap"],
+                   "kv_layout": "gqa_native [1,8,L,128] as the patched attention forward hands K/V over",
+                   "tie_mode": a.tie_mode, "per_layer_us": dt / a.steps / LAYERS * 1e6, "multi_gpu": "replicas, no collective"},
+    }
+    if rank == 0:
+        # ---- roofline of the dominant kernel (K scan), live HIP-event timing ----
+        t_scan = time_scan_kernel(plans, dev)
+        es = 2
+        scan_b, path_b = algorithmic_bytes(cfg["L"], cfg["W"], sum(ks) / len(ks), es)
+        out["roofline"] = {"bound": "hbm", "kernel": "logits_kernel (K scan + window QK^T)", "achieved": scan_b / t_scan / 1e9,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": scan_b / t_scan / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                           "launch_us": t_scan * 1e6, "algorithmic_bytes_per_launch": scan_b,
+                           "path_achieved_GBs": path_b / (dt / a.steps / LAYERS) / 1e9,
+                           "path_frac": path_b / (dt / a.steps / LAYERS) / 1e9 / HBM_PEAK_GBS,
+                           "path_algorithmic_bytes_per_layer": path_b}
+        if not a.no_extras and world == 1:
+            extra = {}
+            other = "torch_cpu" if a.tie_mode == "canonical" else "canonical"
+            try:
+                p2, _ = build_plans(cfg, dev, other, expanded=False)
+                d2 = time_steps(p2, max(2, a.steps // 2), 1, dev, None)
+                extra[f"tokens_per_s_tie_mode_{other}"] = max(2, a.steps // 2) * tokens_per_step / d2
+                del p2
+            except Exception as e:
+                extra[f"tie_mode_{other}_error"] = str(e)
+            try:
+                p3, _ = build_plans(cfg, dev, a.tie_mode, expanded=True)
+                d3 = time_steps(p3, max(2, a.steps // 2), 1, dev, None)
+                extra["tokens_per_s_expanded_kv_as_reference_passes"] = max(2, a.steps // 2) * tokens_per_step / d3
+                del p3
+            except Exception as e:
+                extra["expanded_kv_error"] = str(e)
+            out["extras"] = extra
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

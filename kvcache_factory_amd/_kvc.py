@@ -31,7 +31,7 @@ class KvcError(RuntimeError):
 class Params(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "method", "dtype", "bsz", "n_q_heads", "n_kv_heads", "q_len", "head_dim", "window", "k",
-        "kernel_size", "pooling", "tie_mode", "reserved0", "reserved1")] + [
+        "kernel_size", "pooling", "tie_mode", "debug_stage_mask", "reserved1")] + [
         (n, ctypes.c_int64) for n in (
             "q_stride_b", "q_stride_h", "q_stride_l", "k_stride_b", "k_stride_h", "k_stride_l",
             "v_stride_b", "v_stride_h", "v_stride_l")]
@@ -150,7 +150,7 @@ def compress(method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", 
     sc = torch.empty(bsz, hq, L - window, dtype=k.dtype, device=dev) if (return_scores and scoring) else None
     nbytes = lib().kvc_workspace_bytes(ctypes.byref(p))
     if nbytes == 0 and scoring:
-        _check(lib().kvc_scores(ctypes.byref(p), None, None, None, None, 0, None) or ERR_INVALID)
+        raise KvcError(ERR_INVALID, lib().kvc_last_error().decode())
     ws = workspace(dev, nbytes) if nbytes else None
     _check(lib().kvc_compress(ctypes.byref(p), _ptr(qq), _ptr(k), _ptr(v), _ptr(k_out), _ptr(v_out), _ptr(idx),
                               _ptr(sc), _ptr(ws), nbytes, _stream(dev)))
@@ -173,7 +173,7 @@ def scores(method, q, k, window, kernel_size=5, pooling="avgpool", want_intermed
     sc = torch.empty(bsz, hq, L - window, dtype=q.dtype, device=q.device)
     nbytes = lib().kvc_workspace_bytes(ctypes.byref(p))
     if nbytes == 0:
-        _check(lib().kvc_scores(ctypes.byref(p), None, None, None, None, 0, None) or ERR_INVALID)
+        raise KvcError(ERR_INVALID, lib().kvc_last_error().decode())
     ws = workspace(q.device, nbytes)
     _check(lib().kvc_scores(ctypes.byref(p), _ptr(q), _ptr(k), _ptr(sc), _ptr(ws), nbytes, _stream(q.device)))
     if not want_intermediates:
@@ -219,3 +219,43 @@ def gather(src, idx, window, n_q_heads):
 def pyramid_k(cap, window, q_len, layer_idx, n_layers, beta=20):
     """PyramidKV per-layer budget (pyramidkv_utils.py:205-215): k, or -1 for pass-through."""
     return int(lib().kvc_pyramid_k(cap, window, q_len, layer_idx, n_layers, beta))
+
+
+class CompressPlan:
+    """Everything one update_kv needs, resolved once: params, pointers, outputs and workspace.  `run()` is a single
+    C call that only enqueues kernels on the current stream (used by bench.py and by callers that recompress the
+    same shapes, e.g. one plan per layer)."""
+
+    def __init__(self, method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu",
+                 n_q_heads=None, want_indices=False, want_scores=False):
+        _require_gpu(q, k, v)
+        self.q = _last_dim_contig(q) if q is not None else None
+        self.k, self.v = _last_dim_contig(k), _last_dim_contig(v)
+        dev = self.k.device
+        scoring = method != STREAMINGLLM
+        if scoring:
+            self.p = make_params(method, self.q, self.k, self.v, window, n_keep, kernel_size, pooling, tie_mode)
+            hq = self.q.shape[1]
+        else:
+            hq = n_q_heads if n_q_heads is not None else self.k.shape[1]
+            self.p = make_params(method, None, self.k, self.v, window, n_keep, kernel_size, None, tie_mode)
+            self.p.n_q_heads = hq
+        bsz, L, D = self.k.shape[0], self.k.shape[2], self.k.shape[3]
+        self.k_out = torch.empty(bsz, hq, n_keep + window, D, dtype=self.k.dtype, device=dev)
+        self.v_out = torch.empty_like(self.k_out)
+        self.idx = torch.empty(bsz, hq, n_keep, dtype=torch.int64, device=dev) if (want_indices and scoring) else None
+        self.scores = torch.empty(bsz, hq, L - window, dtype=self.k.dtype, device=dev) if (want_scores and scoring) else None
+        self.nbytes = lib().kvc_workspace_bytes(ctypes.byref(self.p))
+        if self.nbytes == 0 and scoring:
+            raise KvcError(ERR_INVALID, lib().kvc_last_error().decode())
+        self.ws = workspace(dev, self.nbytes) if self.nbytes else None
+        self.dev = dev
+        self._args = (ctypes.byref(self.p), _ptr(self.q if scoring else None), _ptr(self.k), _ptr(self.v),
+                      _ptr(self.k_out), _ptr(self.v_out), _ptr(self.idx), _ptr(self.scores), _ptr(self.ws), self.nbytes)
+        self._fn = lib().kvc_compress
+
+    def run(self, stream=None):
+        rc = self._fn(*self._args, stream if stream is not None else _stream(self.dev))
+        if rc:
+            _check(rc)
+        return self.k_out, self.v_out

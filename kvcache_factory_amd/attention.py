@@ -1,0 +1,104 @@
+"""Patched attention forward — counterpart of the reference's caller template (A13), e.g.
+`llama_sdpa_attn_forward_SnapKV` (pyramidkv/llama_model.py:2020-2135; hot lines of the PyramidKV copy :248-290):
+
+    init_<method>(self)                                   # rebuild self.kv_cluster from self.config every forward
+    q, k, v projections; RoPE                              # unchanged HF code
+    prefill  (this layer's cache is empty):                # reference: key_states.shape[-2] == kv_seq_len (:283)
+        Kc, Vc = self.kv_cluster.update_kv(K, Q, V, attention_mask, num_key_value_groups)       (:285)
+        cache <- Kc, Vc (H_q heads, cap tokens); true length remembered                         (:286,:290)
+        attention of THIS step runs over the uncompressed K, V                                  (:306-313)
+    decode   : append the new token (expanded to H_q heads) and attend over cap + t tokens      (:287-289)
+
+Written against transformers 5.x (single *Attention class, `past_key_values` kwarg, attention dispatched through
+ALL_ATTENTION_FUNCTIONS, DynamicCache of per-layer objects); the reference targets 4.44.2 class names that no
+longer exist (monkeypatch.py:23-25).  K/V go to update_kv UN-expanded (H_kv heads): the kernels read each KV head
+once and still emit the reference's H_q-head compressed cache.
+"""
+from typing import Callable
+
+import torch
+from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
+
+from . import pyramidkv_utils as pu
+from .cache import CompressedDynamicLayer
+
+_INIT = {
+    "pyramidkv": lambda self: pu.init_pyramidkv(self, num_hidden_layers=self.config.num_hidden_layers),
+    "snapkv": pu.init_snapkv,
+    "h2o": pu.init_H2O,
+    "streamingllm": pu.init_StreamingLLM,
+}
+
+
+class _OneGroup:
+    """Stands in for the attention module when K/V already carry H_q heads (decode over the compressed cache):
+    the HF attention functions call repeat_kv(key, module.num_key_value_groups)."""
+
+    def __init__(self, module):
+        self._m = module
+        self.num_key_value_groups = 1
+
+    def __getattr__(self, name):
+        return getattr(self._m, name)
+
+
+def _layer_for(cache, layer_idx):
+    """This layer's cache object, swapped for a CompressedDynamicLayer the first time it is seen empty."""
+    layers = cache.layers
+    while len(layers) <= layer_idx:
+        layers.append(CompressedDynamicLayer())
+    layer = layers[layer_idx]
+    if not isinstance(layer, CompressedDynamicLayer):
+        if layer.get_seq_length() != 0:
+            raise RuntimeError("kvcache_factory_amd: the cache already holds uncompressed tokens for this layer; "
+                               "start generation from an empty cache (the reference resets kv_seq_len the same way, "
+                               "llama_model.py:2609-2612)")
+        layer = CompressedDynamicLayer()
+        layers[layer_idx] = layer
+    return layer
+
+
+def make_forward(method, apply_rotary_pos_emb, eager_attention_forward, repeat_kv, pass_sliding_window=False):
+    init = _INIT[method]
+
+    def forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None, **kwargs):
+        init(self)
+        input_shape = hidden_states.shape[:-1]
+        hidden_shape = (*input_shape, -1, self.head_dim)
+        query_states = self.q_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+        key_states = self.k_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+        value_states = self.v_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+        cos, sin = position_embeddings
+        query_states, key_states = apply_rotary_pos_emb(query_states, key_states, cos, sin)
+
+        attn_module = self
+        if past_key_values is not None:
+            layer = _layer_for(past_key_values, self.layer_idx)
+            if layer.get_seq_length() == 0:                                  # prefill
+                q_len = key_states.shape[-2]
+                kc, vc = self.kv_cluster.update_kv(key_states, query_states, value_states, attention_mask,
+                                                   self.num_key_value_groups)
+                if kc is key_states:                                         # pass-through (q_len < cap): the
+                    kc = repeat_kv(key_states, self.num_key_value_groups)    # reference caches the expanded K/V
+                    vc = repeat_kv(value_states, self.num_key_value_groups)
+                layer.prefill(kc, vc, q_len)
+                # this step's attention sees the full, uncompressed K/V (H_kv heads; the interface expands)
+            else:                                                            # decode over the compressed cache
+                key_states = repeat_kv(key_states, self.num_key_value_groups)
+                value_states = repeat_kv(value_states, self.num_key_value_groups)
+                key_states, value_states = past_key_values.update(key_states, value_states, self.layer_idx)
+                attn_module = _OneGroup(self)
+
+        attention_interface: Callable = ALL_ATTENTION_FUNCTIONS.get_interface(
+            self.config._attn_implementation, eager_attention_forward)
+        extra = {"sliding_window": getattr(self.config, "sliding_window", None)} if pass_sliding_window else {}
+        attn_output, attn_weights = attention_interface(
+            attn_module, query_states, key_states, value_states, attention_mask,
+            dropout=0.0 if not self.training else self.attention_dropout, scaling=self.scaling, **extra, **kwargs)
+        attn_output = attn_output.reshape(*input_shape, -1).contiguous()
+        attn_output = self.o_proj(attn_output)
+        return attn_output, attn_weights
+
+    forward.__name__ = f"kvc_attn_forward_{method}"
+    forward.kvc_method = method
+    return forward

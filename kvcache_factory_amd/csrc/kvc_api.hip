@@ -118,6 +118,7 @@ int enqueue_scores(const kvc_params* p, const Layout& l, const void* q, const vo
     a.q_len = p->q_len; a.window = p->window;
     a.n_tiles = l.n_tiles; a.n_chunks = l.n_chunks;
     a.kernel_size = p->kernel_size; a.pooling = p->pooling;
+    a.stage_mask = p->debug_stage_mask;
     a.sqrt_d = (float)std::sqrt((double)p->head_dim);   // math.sqrt(head_dim) -> fp32 (pyramidkv_utils.py:317)
     const int rc = kvc::launch_scores(a, p->dtype, p->head_dim, st);
     if (rc) return fail(rc, "no scoring kernel for dtype %d head_dim %d", p->dtype, p->head_dim);
@@ -223,6 +224,7 @@ __attribute__((visibility("default"))) int kvc_compress(const kvc_params* p, con
                                                         void* k_out, void* v_out, int64_t* idx_out, void* scores_out,
                                                         void* workspace, size_t workspace_bytes, void* hip_stream) {
     if (int rc = validate(p, true)) return rc;
+    if (p->debug_stage_mask != 0) return fail(KVC_ERR_INVALID, "debug_stage_mask is only honoured by kvc_scores");
     if (!k || !v || !k_out || !v_out) return fail(KVC_ERR_INVALID, "k, v, k_out and v_out must be non-NULL");
     const int es = esize_of(p->dtype);
     if (int rc = check_strides("k", es, p->k_stride_b, p->k_stride_h, p->k_stride_l, k)) return rc;

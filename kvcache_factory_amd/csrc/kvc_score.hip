@@ -318,11 +318,12 @@ __global__ __launch_bounds__(256) void pool_kernel(const ScoreArgs a) {
 // ---------------------------------------------------------------------------------------------
 template <int DT, int WV>
 static void launch_softmax_pool_t(const ScoreArgs& a, hipStream_t st) {
+    const int m = a.stage_mask ? a.stage_mask : 7;
     dim3 g2((unsigned)a.n_chunks, (unsigned)(a.bsz * a.n_q_heads));
-    hipLaunchKernelGGL((rowsum_kernel<DT, WV>), g2, dim3(256), 0, st, a);
+    if (m & 2) hipLaunchKernelGGL((rowsum_kernel<DT, WV>), g2, dim3(256), 0, st, a);
     const int n = a.q_len - a.window;
     dim3 g3((unsigned)((n + 255) / 256), (unsigned)(a.bsz * a.n_q_heads));
-    hipLaunchKernelGGL((pool_kernel<DT, WV>), g3, dim3(256), 0, st, a);
+    if (m & 4) hipLaunchKernelGGL((pool_kernel<DT, WV>), g3, dim3(256), 0, st, a);
 }
 
 template <int DT, int D>
@@ -330,7 +331,7 @@ static int launch_scores_t(const ScoreArgs& a, hipStream_t st) {
     constexpr int ES = Dt<DT>::esize;
     const size_t lds = (size_t)128 * D * ES + 4 * 32 * sizeof(float);
     dim3 g1((unsigned)a.n_tiles, (unsigned)(a.bsz * a.n_kv_heads));
-    hipLaunchKernelGGL((logits_kernel<DT, D>), g1, dim3(256), lds, st, a);
+    if ((a.stage_mask ? a.stage_mask : 7) & 1) hipLaunchKernelGGL((logits_kernel<DT, D>), g1, dim3(256), lds, st, a);
     switch (a.window) {
         case 8:  launch_softmax_pool_t<DT, 8>(a, st); break;
         case 16: launch_softmax_pool_t<DT, 16>(a, st); break;

@@ -1,0 +1,18 @@
+"""Llama attention forwards for the four in-scope methods (reference: pyramidkv/llama_model.py — eager :87,
+sdpa :208/:1305/:1663/:2020 and flash-attn copies of one template).  transformers 5.x has ONE LlamaAttention class
+whose backend is picked at call time, so one forward per method replaces the reference's three."""
+from transformers.models.llama import modeling_llama as _ml
+
+from .attention import make_forward
+
+
+def _mk(method):
+    return make_forward(method, _ml.apply_rotary_pos_emb, _ml.eager_attention_forward, _ml.repeat_kv)
+
+
+llama_attn_forward_PyramidKV = llama_sdpa_attn_forward_PyramidKV = _mk("pyramidkv")
+llama_attn_forward_SnapKV = llama_sdpa_attn_forward_SnapKV = _mk("snapkv")
+llama_attn_forward_H2O = llama_sdpa_attn_forward_H2O = _mk("h2o")
+llama_attn_forward_StreamingLLM = llama_sdpa_attn_forward_StreamingLLM = _mk("streamingllm")
+FORWARDS = {"pyramidkv": llama_attn_forward_PyramidKV, "snapkv": llama_attn_forward_SnapKV,
+            "h2o": llama_attn_forward_H2O, "streamingllm": llama_attn_forward_StreamingLLM}

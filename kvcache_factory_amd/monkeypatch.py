@@ -1,0 +1,37 @@
+"""replace_llama / replace_mistral — drop-in for pyramidkv/monkeypatch.py:19-87, :92-145.
+
+Call once BEFORE building the model, exactly like the reference (run_longbench.py:382-384); the per-layer knobs are
+then written onto `model.model.layers[i].self_attn.config.*` (run_longbench.py:253-261) and read by init_*.
+Methods in scope: "pyramidkv", "snapkv", "h2o", "streamingllm"; "fullkv" leaves the model untouched (:86).
+The reference's other method strings (cam, l2norm, adakv, headkv, think, minference) are out of scope and raise.
+The reference also rebinds `prepare_inputs_for_generation` to reset `kv_seq_len` (llama_model.py:2598-2612); with
+transformers 5.x that bookkeeping lives in the cache layer (cache.CompressedDynamicLayer), so nothing else is patched.
+"""
+import transformers
+
+_IN_SCOPE = ("pyramidkv", "snapkv", "h2o", "streamingllm")
+_OUT_OF_SCOPE = ("cam", "l2norm", "adakv", "headkv", "think", "minference")
+_ORIGINALS = {}
+
+
+def _patch(cls, forwards, method):
+    if method == "fullkv":
+        if cls in _ORIGINALS:
+            cls.forward = _ORIGINALS[cls]
+        return
+    if method in _OUT_OF_SCOPE:
+        raise NotImplementedError(f"method {method!r} is outside this build's scope (SURVEY.md §2 rows 5-11)")
+    if method not in _IN_SCOPE:
+        return                       # reference: unknown strings silently patch nothing (monkeypatch.py:19-87)
+    _ORIGINALS.setdefault(cls, cls.forward)
+    cls.forward = forwards[method]
+
+
+def replace_llama(method, model_name=None):
+    from . import llama_model
+    _patch(transformers.models.llama.modeling_llama.LlamaAttention, llama_model.FORWARDS, method)
+
+
+def replace_mistral(method):
+    from . import mistral_model
+    _patch(transformers.models.mistral.modeling_mistral.MistralAttention, mistral_model.FORWARDS, method)

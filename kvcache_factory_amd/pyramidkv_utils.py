@@ -1,0 +1,155 @@
+"""KV-cluster layer — drop-in for the reference's pyramidkv/pyramidkv_utils.py, compute on MI355X.
+
+Same class names, constructor arguments, `update_kv` signature / return values and error behaviour as
+the reference (file:line below); the ~60 lines of torch ops in each reference `update_kv` are replaced
+by one call into the HIP library (include/kvc.h: kvc_compress).  Differences, all deliberate:
+
+  * `key_states` / `value_states` may carry either H_q heads (the reference's caller repeat_kv()-expands
+    them first, llama_model.py:277-278) or the model's H_kv heads with `num_key_value_groups` =
+    H_q / H_kv — the outputs are identical ([bsz, H_q, cap, D]); the second form reads each KV head once.
+  * the reference prints its budget on every call (pyramidkv_utils.py:217,312,539,601); here that is
+    opt-in: set `kvcache_factory_amd.pyramidkv_utils.VERBOSE = True` (or KVC_VERBOSE=1).
+  * `merge` (LOOK-M pivot merge, :119-170) is out of scope: anything but None raises.
+  * tensors must live on the GPU: there is no CPU / eager fallback.
+"""
+import math  # noqa: F401  (kept for parity with the reference's namespace)
+import os
+
+import torch
+
+from . import _kvc
+
+VERBOSE = os.environ.get("KVC_VERBOSE", "0") == "1"
+TIE_MODE = os.environ.get("KVC_TIE_MODE", "torch_cpu")   # "torch_cpu" (reference-exact ties) | "canonical"
+
+
+def _say(msg):
+    if VERBOSE:
+        print(msg)
+
+
+def _check_merge(merge):
+    if merge is not None:
+        if merge not in ("pivot",):
+            raise ValueError('Merge method not supported')        # pyramidkv_utils.py:164
+        raise NotImplementedError("merge='pivot' (LOOK-M, pyramidkv_utils.py:119-170) is outside this build's scope")
+
+
+def _run(method, key_states, query_states, value_states, window, n_keep, kernel_size, pooling):
+    if pooling not in ("avgpool", "maxpool") and method != _kvc.H2O:
+        raise ValueError('Pooling method not supported')            # pyramidkv_utils.py:333
+    k_out, v_out = _kvc.compress(method, query_states, key_states, value_states, window, n_keep,
+                                 kernel_size, pooling if method != _kvc.H2O else None, TIE_MODE)
+    return k_out, v_out
+
+
+class _KVCluster:
+    """State every reference cluster carries (ctor/reset of pyramidkv_utils.py:174-195, :286-304, :516-531,
+    :579-593): the knobs only — clusters are stateless between calls."""
+
+    _name = "KVCluster"
+
+    def __init__(self, window_size=64, max_capacity_prompt=256 + 64, kernel_size=5, pooling='avgpool', merge=None):
+        self.reset(window_size, max_capacity_prompt, kernel_size, pooling, merge)
+
+    def reset(self, window_size=64, max_capacity_prompt=256 + 64, kernel_size=5, pooling='avgpool', merge=None):
+        assert max_capacity_prompt - window_size > 0                       # :289
+        self.window_size, self.max_capacity_prompt = window_size, max_capacity_prompt
+        self.kernel_size, self.pooling, self.merge = kernel_size, pooling, merge
+
+    def _prefill_shapes(self, key_states, query_states):
+        assert key_states.shape[-2] == query_states.shape[-2]              # :309 "check if prefix phase"
+        return query_states.shape                                          # bsz, num_heads, q_len, head_dim
+
+    def _budget(self, q_len):
+        return self.max_capacity_prompt - self.window_size                 # k of .topk(k) at :334
+
+    _method = None
+
+    def update_kv(self, key_states, query_states, value_states, attention_mask, num_key_value_groups):
+        """(key_states', value_states') — `attention_mask` and `num_key_value_groups` are accepted and, as in the
+        reference (:322 shadows the former, the latter is never read), do not influence the result."""
+        bsz, num_heads, q_len, head_dim = self._prefill_shapes(key_states, query_states)
+        n_keep = self._budget(q_len)
+        _say(f"{self._name} max_capacity_prompt {n_keep if self._method == _kvc.PYRAMIDKV else self.max_capacity_prompt}")
+        if q_len < self.max_capacity_prompt:                               # :314 pass-through, same objects
+            return key_states, value_states
+        _check_merge(self.merge)
+        if self._method == _kvc.STREAMINGLLM:
+            return _kvc.compress(_kvc.STREAMINGLLM, None, key_states, value_states, self.window_size, n_keep,
+                                 n_q_heads=num_heads)
+        return _run(self._method, key_states, query_states, value_states, self.window_size, n_keep,
+                    self.kernel_size, self.pooling)
+
+
+class SnapKVCluster(_KVCluster):
+    """pyramidkv_utils.py:285-347."""
+    _name, _method = "SnapKV", _kvc.SNAPKV
+
+    def __init__(self, window_size=64, max_capacity_prompt=256 + 64, kernel_size=5, pooling='avgpool', merge=None,
+                 recent_size=32, ratio=0.4):
+        super().__init__(window_size, max_capacity_prompt, kernel_size, pooling, merge)
+        self.recent_size, self.ratio = recent_size, ratio                  # ThinK knobs, unused on this path
+
+
+class PyramidKVCluster(_KVCluster):
+    """pyramidkv_utils.py:173-283: SnapKV's body with a per-layer budget (:205-215)."""
+    _name, _method = "PyramidKV", _kvc.PYRAMIDKV
+
+    def __init__(self, num_hidden_layers=32, window_size=64, max_capacity_prompt=256 + 64, kernel_size=5,
+                 pooling='avgpool', beta=20, num_layers=80, layer_idx=None, merge=None):
+        super().__init__(window_size, max_capacity_prompt, kernel_size, pooling, merge)
+        self.layer_idx, self.num_hidden_layers = layer_idx, num_hidden_layers
+        self.steps, self.beta = -1, beta
+
+    def _budget(self, q_len):
+        """k for this layer; -1 = pass-through.  Host arithmetic lives in the C library (kvc_pyramid_k)."""
+        return _kvc.pyramid_k(self.max_capacity_prompt, self.window_size, q_len, self.layer_idx,
+                              self.num_hidden_layers, self.beta)
+
+    layer_budget = _budget
+
+
+class H2OKVCluster(_KVCluster):
+    """pyramidkv_utils.py:515-575: every query row scores; kernel_size / pooling are ignored (:555-561)."""
+    _name, _method = "H2O", _kvc.H2O
+
+
+class StreamingLLMKVCluster(_KVCluster):
+    """pyramidkv_utils.py:578-620: no scoring, keeps the first cap-W and the last W tokens."""
+    _name, _method = "StreamingLLM", _kvc.STREAMINGLLM
+
+
+# ---- init_* factories (pyramidkv_utils.py:880-1031): default-fill self.config on first use, then rebuild
+# ---- self.kv_cluster on EVERY forward so config edits between prompts take effect (clusters are stateless).
+_DEFAULTS = (("window_size", 32), ("kernel_size", 5), ("pooling", "avgpool"), ("merge", None))
+
+
+def _init(self, cls, default_cap, **extra):
+    if not hasattr(self, "kv_cluster"):
+        for name, val in _DEFAULTS + (("max_capacity_prompt", default_cap),):
+            if not hasattr(self.config, name):
+                setattr(self.config, name, val)
+    c = self.config
+    self.kv_cluster = cls(window_size=c.window_size, max_capacity_prompt=c.max_capacity_prompt,
+                          kernel_size=c.kernel_size, pooling=c.pooling, merge=c.merge, **extra)
+
+
+def init_pyramidkv(self, num_hidden_layers):
+    """pyramidkv_utils.py:880-902 (default cap 2048)."""
+    _init(self, PyramidKVCluster, 2048, num_hidden_layers=num_hidden_layers, layer_idx=self.layer_idx)
+
+
+def init_snapkv(self):
+    """pyramidkv_utils.py:904-924 (default cap 4096)."""
+    _init(self, SnapKVCluster, 4096)
+
+
+def init_H2O(self):
+    """pyramidkv_utils.py:990-1009 (default cap 2048)."""
+    _init(self, H2OKVCluster, 2048)
+
+
+def init_StreamingLLM(self):
+    """pyramidkv_utils.py:1011-1031 (default cap 2048)."""
+    _init(self, StreamingLLMKVCluster, 2048)

@@ -1,0 +1,190 @@
+"""Generate tests/golden/* from the REAL reference (this container only).
+
+Imports /root/reference/pyramidkv/pyramidkv_utils.py (pure Python + torch CPU; SURVEY.md §8c: importable,
+no denial) and runs its own cluster classes on inputs regenerated from kvcache_factory_amd.synth, the
+portable counter-based generator — so fixtures hold only OUTPUTS (pooled scores captured at the
+reference's own `.topk` call, top-k values and indices, SHA-256 of K'/V') plus the case parameters.
+Nothing from the reference's source text is stored.  The reference never travels to the GPU box.
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz + manifest.json
+"""
+import contextlib
+import hashlib
+import io
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from kvcache_factory_amd import synth  # noqa: E402
+import pyramidkv.pyramidkv_utils as ref  # noqa: E402  (the reference itself)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
+
+
+def raw_bits(t):
+    t = t.contiguous()
+    return t.view(torch.int32 if t.dtype == torch.float32 else torch.int16).numpy()
+
+
+def sha(t):
+    return hashlib.sha256(raw_bits(t).tobytes()).hexdigest()
+
+
+class TopkTap:
+    """Record the tensor the reference hands to .topk (the pooled scores, pyramidkv_utils.py:334) and its result."""
+
+    def __enter__(self):
+        self.orig = torch.Tensor.topk
+        self.calls = []
+        tap = self
+
+        def topk(t, *a, **kw):
+            r = tap.orig(t, *a, **kw)
+            tap.calls.append((t.detach().clone(), r.values.detach().clone(), r.indices.detach().clone()))
+            return r
+        torch.Tensor.topk = topk
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.topk = self.orig
+
+
+def make_cluster(c):
+    kw = dict(window_size=c["W"], max_capacity_prompt=c["cap"], kernel_size=c["kernel"], pooling=c["pooling"])
+    m = c["method"]
+    if m == "snapkv":
+        return ref.SnapKVCluster(**kw)
+    if m == "pyramidkv":
+        return ref.PyramidKVCluster(num_hidden_layers=c["n_layers"], layer_idx=c["layer_idx"], **kw)
+    if m == "h2o":
+        return ref.H2OKVCluster(**kw)
+    if m == "streamingllm":
+        return ref.StreamingLLMKVCluster(**kw)
+    raise ValueError(m)
+
+
+def run_case(c, store_scores):
+    dtype = DT[c["dtype"]]
+    q, k, v = synth.make_qkv(c["Hq"], c["Hkv"], c["L"], c["D"], dtype, c["seed"], peaky=c.get("peaky", False),
+                             expanded=True)
+    if c.get("zero_q"):          # all-equal scores: every logit 0 -> uniform softmax
+        q = torch.zeros_like(q)
+    if c.get("scale_q"):         # large |logits| (fp16 large-negative regime)
+        q = (q.float() * c["scale_q"]).to(dtype)
+    cl = make_cluster(c)
+    t0 = time.time()
+    with TopkTap() as tap, contextlib.redirect_stdout(io.StringIO()):
+        ko, vo = cl.update_kv(k, q, v, None, c["Hq"] // c["Hkv"])
+    dt = time.time() - t0
+    out = {}
+    meta = dict(c)
+    meta["ref_seconds"] = round(dt, 4)
+    meta["passthrough"] = bool(ko is k and vo is v)
+    meta["out_shape"] = list(ko.shape)
+    meta["k_out_sha256"], meta["v_out_sha256"] = sha(ko), sha(vo)
+    if tap.calls:
+        sc, val, idx = tap.calls[0]
+        meta["n_keep"] = int(idx.shape[-1])
+        meta["scores_sha256"] = sha(sc[0])
+        out["indices"] = idx[0].numpy().astype(np.int64)
+        out["values"] = raw_bits(val[0])
+        if store_scores:
+            out["scores"] = raw_bits(sc[0])
+    elif c["method"] == "streamingllm" and not meta["passthrough"]:
+        meta["n_keep"] = c["cap"] - c["W"]
+    return meta, out
+
+
+def cases():
+    cs = []
+
+    def add(name, **kw):
+        base = dict(method="snapkv", dtype="bf16", Hq=4, Hkv=2, L=257, D=128, W=8, cap=40, kernel=7, pooling="maxpool",
+                    seed=len(cs) + 1, layer_idx=0, n_layers=32)
+        base.update(kw)
+        base["name"] = name
+        cs.append(base)
+
+    # ---- small cases: methods x dtypes x pooling x W (inputs regenerated, scores stored in full) ----
+    for dt in ("bf16", "fp16", "fp32"):
+        for pool, ks in (("maxpool", 7), ("avgpool", 5)):
+            for W in (8, 32):
+                add(f"snap_{dt}_{pool}_W{W}_L257_D64", dtype=dt, pooling=pool, kernel=ks, W=W, cap=W + 40, L=257, D=64)
+                add(f"snap_{dt}_{pool}_W{W}_L1024_D128", dtype=dt, pooling=pool, kernel=ks, W=W, cap=W + 120, L=1024, D=128, Hkv=1)
+                add(f"snap_{dt}_{pool}_W{W}_L96_D128_peaky", dtype=dt, pooling=pool, kernel=ks, W=W, cap=W + 24, L=96, D=128, Hkv=4, peaky=True)
+        for layer in (0, 15, 16, 31):
+            add(f"pyr_{dt}_layer{layer}_L1024", method="pyramidkv", dtype=dt, layer_idx=layer, L=1024, cap=72, W=8, Hkv=2)
+        add(f"h2o_{dt}_W8_L257", method="h2o", dtype=dt, L=257, D=64, W=8, cap=48)
+        add(f"h2o_{dt}_W32_L300", method="h2o", dtype=dt, L=300, D=128, W=32, cap=64, Hq=2, Hkv=1)
+        add(f"stream_{dt}_L1000", method="streamingllm", dtype=dt, L=1000, D=128, W=60, cap=64, Hq=8, Hkv=2)
+    # ---- edge cases ----
+    add("edge_passthrough_snap", L=30, cap=40, W=8)
+    add("edge_passthrough_pyr", method="pyramidkv", L=30, cap=40, W=8)
+    add("edge_passthrough_h2o", method="h2o", L=30, cap=40, W=8)
+    add("edge_passthrough_stream", method="streamingllm", L=30, cap=40, W=8)
+    add("edge_qlen_eq_cap", L=32, cap=32, W=8, D=64)                       # k == n: all kept, permuted
+    add("edge_qlen_eq_cap_fp32_avg", L=32, cap=32, W=8, D=64, dtype="fp32", pooling="avgpool", kernel=5)
+    add("edge_pyr_middle_branch", method="pyramidkv", L=100, cap=72, W=8, layer_idx=7)     # cap <= L < 2(cap-W)
+    add("edge_pyr_clamped_maxnum", method="pyramidkv", L=128, cap=72, W=8, layer_idx=0, n_layers=4)   # L == 2(cap-W)
+    add("edge_pyr_clamped_deep", method="pyramidkv", L=128, cap=72, W=8, layer_idx=3, n_layers=4)
+    add("edge_pyr_tiny_k", method="pyramidkv", L=400, cap=48, W=8, layer_idx=31, n_layers=32)
+    add("edge_pyr_k2", method="pyramidkv", L=400, cap=48, W=8, layer_idx=1, n_layers=2)
+    add("edge_k64_eq_n", L=648, cap=18, W=8, D=64)                         # n=640, k=10: k*64 == n -> partial_sort
+    add("edge_k64_gt_n", L=648, cap=19, W=8, D=64)                         # n=640, k=11: nth_element + sort
+    add("edge_all_equal_scores", L=257, cap=40, W=8, zero_q=True)
+    add("edge_all_equal_scores_avg_fp32", L=257, cap=40, W=8, zero_q=True, dtype="fp32", pooling="avgpool", kernel=5)
+    add("edge_fp16_large_logits", dtype="fp16", L=257, cap=40, W=8, scale_q=40.0)
+    add("edge_bf16_large_logits", dtype="bf16", L=257, cap=40, W=8, scale_q=40.0)
+    add("edge_kernel1", L=257, cap=40, W=8, kernel=1, pooling="maxpool")
+    add("edge_fp32_avg_tiefree", dtype="fp32", L=1024, cap=136, W=8, pooling="avgpool", kernel=5, D=128)
+    add("edge_W64_default_lib", L=640, cap=320, W=64, pooling="avgpool", kernel=5, Hq=2, Hkv=1)
+    # ---- config-size cases (BASELINE.json configs; only indices/values/hashes are stored) ----
+    big = dict(Hq=32, Hkv=8, D=128, W=8, kernel=7, pooling="maxpool")
+    add("C1_streamingllm_L1000", method="streamingllm", L=1000, cap=64, W=60, Hq=32, Hkv=8, D=128, seed=0)
+    add("C2_snapkv_8k_bf16", L=8000, cap=128, seed=0, **big)
+    add("C2_snapkv_8k_fp16", L=8000, cap=128, dtype="fp16", seed=0, **big)
+    add("C2_snapkv_8k_bf16_peaky", L=8000, cap=128, seed=1, peaky=True, **big)
+    add("C2_snapkv_8k_bf16_W32", L=8000, cap=128, seed=0, Hq=32, Hkv=8, D=128, W=32, kernel=7, pooling="maxpool")
+    for layer in (0, 15, 16, 31):
+        add(f"C4_pyramidkv_8k_layer{layer}", method="pyramidkv", L=8000, cap=128, layer_idx=layer, seed=0, **big)
+    add("C3_h2o_8k_2heads", method="h2o", L=8000, cap=128, Hq=2, Hkv=1, D=128, W=8, seed=0)
+    for layer in (0, 28, 31):
+        add(f"C5_pyramidkv_32k_layer{layer}", method="pyramidkv", L=32000, cap=2048, layer_idx=layer, seed=0, **big)
+    return cs
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1:]
+    manifest = {}
+    mpath = os.path.join(OUT, "manifest.json")
+    if only and os.path.exists(mpath):
+        manifest = json.load(open(mpath))
+    torch.set_num_threads(8)
+    for c in cases():
+        if only and not any(o in c["name"] for o in only):
+            continue
+        small = c["L"] <= 1100 and c["Hq"] <= 8
+        t0 = time.time()
+        meta, arrays = run_case(c, store_scores=small)
+        manifest[c["name"]] = meta
+        if arrays:
+            np.savez_compressed(os.path.join(OUT, c["name"] + ".npz"), **arrays)
+        print(f"{c['name']:45s} {time.time() - t0:7.1f}s keep={meta.get('n_keep')} pass={meta['passthrough']}", flush=True)
+    meta_env = {"torch": torch.__version__, "generated_by": "oracle/gen_golden.py",
+                "reference": "assassin808/KVCache-Factory @ 2025-02-18, pyramidkv/pyramidkv_utils.py"}
+    manifest["_env"] = meta_env
+    json.dump(manifest, open(mpath, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,26 @@
+"""TEST-ONLY stand-in for kvcache_factory_amd._kvc.compress backed by the CPU oracle, so the host-side plumbing
+(cluster classes, patched attention forward, cache layer) can be exercised without a GPU.  Never shipped."""
+import torch
+
+from kvcache_factory_amd import _kvc
+from oracle import kvc_oracle as O
+
+
+def oracle_compress(method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu",
+                    n_q_heads=None, return_indices=False, return_scores=False):
+    assert k.shape[0] == 1
+    k, v = k.contiguous(), v.contiguous()
+    if method == _kvc.STREAMINGLLM:
+        hq = n_q_heads if n_q_heads is not None else k.shape[1]
+        ko, vo, idx = O.streaming(k, v, window, n_keep, hq)
+        sc = None
+    else:
+        tm = O.TIES_TORCH if tie_mode in ("torch_cpu", 0) else O.TIES_CANON
+        ko, vo, idx, sc = O.compress(q, k, v, window, n_keep, kernel_size, pooling if method != _kvc.H2O else "avgpool",
+                                     full_rows=method == _kvc.H2O, dot_mode=O.DOT_CHAIN, sum_mode=O.SUM_KVC, tie_mode=tm)
+    out = [ko, vo]
+    if return_indices:
+        out.append(idx[None])
+    if return_scores:
+        out.append(sc[None] if sc is not None else None)
+    return tuple(out)

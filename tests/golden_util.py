@@ -1,0 +1,66 @@
+"""Helpers shared by the parity tests: load tests/golden fixtures (generated from the imported reference by
+oracle/gen_golden.py) and regenerate their inputs with the portable generator."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import torch
+
+from kvcache_factory_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
+
+with open(os.path.join(GOLDEN, "manifest.json")) as _f:
+    MANIFEST = {k: v for k, v in json.load(_f).items() if not k.startswith("_")}
+
+
+def names(pred=lambda m: True):
+    return sorted(n for n, m in MANIFEST.items() if pred(m))
+
+
+def inputs(meta, device="cpu", expanded=True):
+    """Regenerate (q, k, v) of a fixture exactly as oracle/gen_golden.py fed them to the reference."""
+    dtype = DT[meta["dtype"]]
+    q, k, v = synth.make_qkv(meta["Hq"], meta["Hkv"], meta["L"], meta["D"], dtype, meta["seed"],
+                             peaky=meta.get("peaky", False), expanded=expanded, device=device)
+    if meta.get("zero_q"):
+        q = torch.zeros_like(q)
+    if meta.get("scale_q"):
+        q = (q.float() * meta["scale_q"]).to(dtype)
+    return q, k, v
+
+
+def arrays(name):
+    p = os.path.join(GOLDEN, name + ".npz")
+    return dict(np.load(p)) if os.path.exists(p) else {}
+
+
+def from_bits(a, dtype):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.view(dtype)
+
+
+def bits(t):
+    t = t.detach().cpu().contiguous()
+    return t.view(torch.int32 if t.dtype == torch.float32 else torch.int16)
+
+
+def sha(t):
+    return hashlib.sha256(bits(t).numpy().tobytes()).hexdigest()
+
+
+def ulp_diff(a, b):
+    """Elementwise distance in units of the dtype's last place (monotone integer mapping of the bit patterns)."""
+    def key(t):
+        i = bits(t).to(torch.int64)
+        nb = 32 if t.dtype == torch.float32 else 16
+        sign = 1 << (nb - 1)
+        i = i & ((1 << nb) - 1)
+        return torch.where(i >= sign, sign - 1 - (i - sign), i + sign - 1 + 1)
+    return (key(a) - key(b)).abs()
+
+
+def pool_name(meta):
+    return None if meta["method"] == "h2o" else meta["pooling"]

@@ -1,0 +1,190 @@
+"""Host-side plumbing (A0, A12-A15) without a GPU: cluster classes, init_* factories, replace_llama/replace_mistral,
+the patched attention forward and the true-length cache layer.  The HIP call is replaced by the CPU oracle through
+tests/cpu_compress.py (test-only injection; the product itself has no CPU path).
+
+Includes BASELINE.json config C1: StreamingLLM on a Llama-3-8B-shaped 1-layer model, seq_len=1000, budget=64,
+window = cap-4 = 60 (run_longbench.py:220-223), sdpa on CPU."""
+import pytest
+import torch
+
+import golden_util as G
+from cpu_compress import oracle_compress
+from kvcache_factory_amd import _kvc, monkeypatch as mp, pyramidkv_utils as pu
+
+
+@pytest.fixture()
+def cpu_backend(monkeypatch, oracle):
+    monkeypatch.setattr(_kvc, "compress", oracle_compress)
+    yield
+
+
+def _llama(layers=1, dtype=torch.float32):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = LlamaConfig(hidden_size=4096, intermediate_size=512, num_hidden_layers=layers, num_attention_heads=32,
+                      num_key_value_heads=8, head_dim=128, vocab_size=512, max_position_embeddings=8192,
+                      attn_implementation="sdpa")
+    torch.manual_seed(0)
+    return LlamaForCausalLM(cfg).to(dtype).eval()
+
+
+def _set_knobs(model, **kw):
+    for layer in model.model.layers:                     # run_longbench.py:253-261
+        for k, v in kw.items():
+            setattr(layer.self_attn.config, k, v)
+
+
+def test_clusters_passthrough_returns_same_objects(cpu_backend):
+    """q_len < cap: the very same tensor objects come back (pyramidkv_utils.py:314-315, :218, :541, :603)."""
+    q, k, v = (torch.randn(1, 4, 30, 64) for _ in range(3))
+    for c in (pu.SnapKVCluster(8, 40), pu.H2OKVCluster(8, 40), pu.StreamingLLMKVCluster(8, 40),
+              pu.PyramidKVCluster(num_hidden_layers=4, window_size=8, max_capacity_prompt=40, layer_idx=1)):
+        ko, vo = c.update_kv(k, q, v, None, 1)
+        assert ko is k and vo is v
+
+
+def test_cluster_errors_match_reference(cpu_backend):
+    with pytest.raises(AssertionError):
+        pu.SnapKVCluster(window_size=64, max_capacity_prompt=64)             # :289
+    q, k, v = (torch.randn(1, 2, 64, 64) for _ in range(3))
+    with pytest.raises(AssertionError):
+        pu.SnapKVCluster(8, 40).update_kv(k[:, :, :50], q, v, None, 1)       # :309
+    with pytest.raises(ValueError, match="Pooling method not supported"):
+        pu.SnapKVCluster(8, 40, pooling="median").update_kv(k, q, v, None, 1)   # :333
+    with pytest.raises(ValueError, match="Merge method not supported"):
+        pu.SnapKVCluster(8, 40, merge="bogus").update_kv(k, q, v, None, 1)      # :164
+    with pytest.raises(NotImplementedError):
+        pu.SnapKVCluster(8, 40, merge="pivot").update_kv(k, q, v, None, 1)
+    # H2O ignores pooling entirely (:555-561)
+    ko, vo = pu.H2OKVCluster(8, 40, pooling="median").update_kv(k, q, v, None, 1)
+    assert ko.shape == (1, 2, 40, 64)
+
+
+@pytest.mark.parametrize("name", ["snap_fp32_maxpool_W8_L257_D64", "pyr_bf16_layer15_L1024", "h2o_fp16_W8_L257",
+                                  "stream_bf16_L1000", "edge_qlen_eq_cap", "edge_pyr_middle_branch"])
+def test_cluster_update_kv_matches_reference_fixture(cpu_backend, name):
+    """Cluster API end to end (expanded K/V exactly as the reference's caller passes them, and GQA-native)."""
+    m = G.MANIFEST[name]
+    q, k, v = G.inputs(m)
+    kw = dict(window_size=m["W"], max_capacity_prompt=m["cap"], kernel_size=m["kernel"], pooling=m["pooling"])
+    cls = {"snapkv": pu.SnapKVCluster, "h2o": pu.H2OKVCluster, "streamingllm": pu.StreamingLLMKVCluster,
+           "pyramidkv": lambda **a: pu.PyramidKVCluster(num_hidden_layers=m["n_layers"], layer_idx=m["layer_idx"], **a)}[m["method"]]
+    g = m["Hq"] // m["Hkv"]
+    for kk, vv in ((k, v), (k[:, ::g].contiguous(), v[:, ::g].contiguous())):
+        ko, vo = cls(**kw).update_kv(kk, q, vv, None, g)
+        assert list(ko.shape) == m["out_shape"]
+        assert G.sha(ko) == m["k_out_sha256"] and G.sha(vo) == m["v_out_sha256"]
+
+
+def test_init_factories_rebuild_cluster_every_forward(cpu_backend):
+    """init_* default-fill once and rebuild kv_cluster on every call (pyramidkv_utils.py:880-1031)."""
+    class Cfg:
+        pass
+
+    class Attn:
+        def __init__(self):
+            self.config, self.layer_idx = Cfg(), 3
+    a = Attn()
+    pu.init_snapkv(a)
+    assert (a.config.window_size, a.config.max_capacity_prompt, a.config.kernel_size, a.config.pooling) == (32, 4096, 5, "avgpool")
+    first = a.kv_cluster
+    a.config.max_capacity_prompt = 128
+    pu.init_snapkv(a)
+    assert a.kv_cluster is not first and a.kv_cluster.max_capacity_prompt == 128
+    b = Attn()
+    pu.init_pyramidkv(b, num_hidden_layers=32)
+    assert b.config.max_capacity_prompt == 2048 and b.kv_cluster.layer_idx == 3 and b.kv_cluster.num_hidden_layers == 32
+    c = Attn(); pu.init_H2O(c); assert isinstance(c.kv_cluster, pu.H2OKVCluster) and c.config.max_capacity_prompt == 2048
+    d = Attn(); pu.init_StreamingLLM(d); assert isinstance(d.kv_cluster, pu.StreamingLLMKVCluster)
+
+
+def test_replace_llama_and_mistral_rebind_and_restore():
+    import transformers
+    LA = transformers.models.llama.modeling_llama.LlamaAttention
+    MA = transformers.models.mistral.modeling_mistral.MistralAttention
+    orig_l, orig_m = LA.forward, MA.forward
+    try:
+        for method in ("pyramidkv", "snapkv", "h2o", "streamingllm"):
+            mp.replace_llama(method); mp.replace_mistral(method)
+            assert LA.forward.kvc_method == method and MA.forward.kvc_method == method
+        mp.replace_llama("no-such-method")               # unknown strings patch nothing (monkeypatch.py:19-87)
+        assert LA.forward.kvc_method == "streamingllm"
+        with pytest.raises(NotImplementedError):
+            mp.replace_llama("adakv")
+    finally:
+        mp.replace_llama("fullkv"); mp.replace_mistral("fullkv")
+    assert LA.forward is orig_l and MA.forward is orig_m
+
+
+def _generate(model, ids, n):
+    with torch.no_grad():
+        return model.generate(ids, max_new_tokens=n, do_sample=False, use_cache=True, return_dict_in_generate=True)
+
+
+def test_c1_streamingllm_llama3_8b_shape_one_layer(cpu_backend):
+    """BASELINE config C1 (plumbing): cache holds tokens 0-3 + the last 60 for all 32 heads, the prefill step
+    attends over the uncompressed K/V (first new token identical to full-KV), decode continues at the true length."""
+    model = _llama(1)
+    ids = torch.randint(0, 512, (1, 1000), generator=torch.Generator().manual_seed(1))
+    full = _generate(model, ids, 3)
+    full_k = full.past_key_values.layers[0].keys            # [1, 8, 1003, 128]
+    try:
+        mp.replace_llama("streamingllm")
+        _set_knobs(model, window_size=60, max_capacity_prompt=64, kernel_size=7, pooling="maxpool")
+        seen = {}
+        orig = pu.StreamingLLMKVCluster.update_kv
+
+        def spy(self, k, q, v, am, g):
+            seen["k"], seen["q_strides"] = k, q.stride()
+            return orig(self, k, q, v, am, g)
+        pu.StreamingLLMKVCluster.update_kv = spy
+        out = _generate(model, ids, 3)
+    finally:
+        pu.StreamingLLMKVCluster.update_kv = orig
+        mp.replace_llama("fullkv")
+    layer = out.past_key_values.layers[0]
+    assert layer.get_seq_length() == 1002 and layer.keys.shape == (1, 32, 64 + 2, 128)
+    assert seen["k"].shape == (1, 8, 1000, 128)                       # GQA-native hand-off
+    assert seen["q_strides"][1:] == (128, 4096, 1)                    # q arrives in [L, H, D] memory order
+    expect = torch.cat([full_k[:, :, :4], full_k[:, :, 940:1000]], dim=2).repeat_interleave(4, dim=1)
+    assert torch.equal(layer.keys[:, :, :64], expect)
+    assert out.sequences[0, 1000] == full.sequences[0, 1000]           # prefill logits unaffected by eviction
+    assert out.sequences.shape == full.sequences.shape
+
+
+@pytest.mark.parametrize("method,cls", [("snapkv", "SnapKVCluster"), ("pyramidkv", "PyramidKVCluster"), ("h2o", "H2OKVCluster")])
+def test_scored_methods_through_the_model(cpu_backend, method, cls):
+    """The tensors captured at update_kv, fed to the oracle directly, give exactly what the cache then holds; decode
+    positions continue from the true prompt length."""
+    model = _llama(2)
+    L, cap, W = 160, 48, 8
+    ids = torch.randint(0, 512, (1, L), generator=torch.Generator().manual_seed(2))
+    calls = []
+    klass = getattr(pu, cls)
+    orig = klass.update_kv
+
+    def spy(self, k, q, v, am, g):
+        r = orig(self, k, q, v, am, g)
+        calls.append((self, k.clone(), q.clone(), v.clone(), r[0].clone()))
+        return r
+    pos_seen = []
+    def rope_hook(mod, args, kwargs, out):
+        pos_seen.append((kwargs.get("position_ids") if "position_ids" in kwargs else args[1]).clone())
+    hook = model.model.rotary_emb.register_forward_hook(rope_hook, with_kwargs=True)
+    try:
+        mp.replace_llama(method)
+        _set_knobs(model, window_size=W, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool")
+        klass.update_kv = spy
+        out = _generate(model, ids, 2)
+    finally:
+        klass.update_kv = orig
+        hook.remove()
+        mp.replace_llama("fullkv")
+    assert len(calls) == 2                                              # one compression per layer, prefill only
+    for li, (cl, k, q, v, kc) in enumerate(calls):
+        n_keep = cl._budget(L)
+        ko, vo, idx, sc = oracle_compress(cl._method, q, k, v, W, n_keep, 7, "maxpool", return_indices=True, return_scores=True)
+        assert torch.equal(kc, ko)
+        layer = out.past_key_values.layers[li]
+        assert torch.equal(layer.keys[:, :, :n_keep + W], ko) and layer.get_seq_length() == L + 1
+        assert layer.keys.shape[2] == n_keep + W + 1
+    assert [int(p[0, 0]) for p in pos_seen] == [0, L]                   # prefill at 0.., decode at the TRUE length
