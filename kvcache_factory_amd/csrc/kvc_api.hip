@@ -25,7 +25,7 @@ inline int esize_of(int dtype) { return dtype == KVC_FP32 ? 4 : 2; }
 inline bool scoring(int method) { return method == KVC_SNAPKV || method == KVC_PYRAMIDKV || method == KVC_H2O; }
 
 struct Layout {
-    size_t logits, pmax, psum, rowmax, rowsum, scores, idx, total;
+    size_t logits, pmax, psum, rowmax, rowsum, scores, idx, exact, total;
     int n_tiles, n_chunks;
 };
 
@@ -82,6 +82,9 @@ Layout carve(const kvc_params* p) {
         l.rowsum = off; off = align_up(off + heads * W * 4, 256);
         l.scores = off; off = align_up(off + heads * n * es, 256);
         l.idx = off;    off = align_up(off + heads * (size_t)p->k * 8, 256);
+        l.exact = off;
+        if (p->tie_mode == KVC_TIES_TORCH_CPU)
+            off = align_up(off + kvc::select_exact_scratch_bytes((int)heads, (int)n, p->k), 256);
     }
     l.total = off;
     return l;
@@ -125,21 +128,7 @@ int enqueue_scores(const kvc_params* p, const Layout& l, const void* q, const vo
     return hip_ok("scores launch");
 }
 
-int enqueue_select(const kvc_params* p, const void* scores, int64_t* idx, hipStream_t st) {
-    if (p->k == 0) return KVC_OK;
-    if (p->k > 16384) return fail(KVC_ERR_UNSUPPORTED, "k=%d > 16384: the LDS sort of the selected set is not built for it", p->k);
-    kvc::SelectArgs s;
-    s.scores = scores; s.idx = idx;
-    s.n = p->q_len - p->window; s.k = p->k; s.heads = p->bsz * p->n_q_heads;
-    s.pow2 = 1;
-    while (s.pow2 < s.k) s.pow2 <<= 1;
-    const int rc = kvc::launch_select(s, p->dtype, p->tie_mode, st);
-    if (rc == KVC_ERR_UNSUPPORTED) return fail(rc, "tie_mode %d not built for this shape", p->tie_mode);
-    if (rc) return fail(rc, "select launch failed");
-    return hip_ok("select launch");
-}
-
-int enqueue_gather(const kvc_params* p, const void* src, int64_t sb, int64_t sh, int64_t sl, const int64_t* idx, void* out, hipStream_t st) {
+kvc::GatherArgs gather_args(const kvc_params* p, const void* src, int64_t sb, int64_t sh, int64_t sl, const int64_t* idx, void* out) {
     kvc::GatherArgs g;
     g.src = src; g.out = out; g.idx = idx;
     g.stride_b = sb; g.stride_h = sh; g.stride_l = sl;
@@ -147,7 +136,40 @@ int enqueue_gather(const kvc_params* p, const void* src, int64_t sb, int64_t sh,
     g.q_len = p->q_len; g.window = p->window; g.k = p->k;
     g.esize = esize_of(p->dtype);
     g.row_bytes = p->head_dim * g.esize;
-    kvc::launch_gather(g, st);
+    return g;
+}
+
+// A7 (+ A8 in the same kernel when gk/gv are given and k is small).
+int enqueue_select(const kvc_params* p, const void* scores, int64_t* idx, const kvc::GatherArgs* gk, const kvc::GatherArgs* gv,
+                   void* exact_scratch, hipStream_t st) {
+    if (p->k == 0) return KVC_OK;
+    if (p->k > 16384) return fail(KVC_ERR_UNSUPPORTED, "k=%d > 16384: the LDS sort of the selected set is not built for it", p->k);
+    if (p->q_len - p->window > 65536) return fail(KVC_ERR_UNSUPPORTED, "more than 65536 candidates per head not built");
+    kvc::SelectArgs s;
+    std::memset(&s, 0, sizeof(s));
+    s.scores = scores; s.idx = idx;
+    s.n = p->q_len - p->window; s.k = p->k; s.heads = p->bsz * p->n_q_heads;
+    s.pow2 = 1;
+    while (s.pow2 < s.k) s.pow2 <<= 1;
+    if (gk && gv) { s.fuse = 1; s.gk = *gk; s.gv = *gv; }
+    if (p->tie_mode == KVC_TIES_TORCH_CPU) {
+        const int rc = kvc::launch_select_exact(s, p->dtype, exact_scratch, st);
+        if (rc == KVC_ERR_WORKSPACE) return fail(rc, "tie_mode torch_cpu at n=%d needs the workspace (kvc_workspace_bytes)", s.n);
+        if (rc) return fail(rc, "exact select launch failed");
+        return hip_ok("exact select launch");
+    }
+    const int rc = kvc::launch_select(s, p->dtype, p->tie_mode, st);
+    if (rc == KVC_ERR_UNSUPPORTED) return fail(rc, "tie_mode %d not built for this shape", p->tie_mode);
+    if (rc) return fail(rc, "select launch failed");
+    return hip_ok("select launch");
+}
+
+int enqueue_gather(const kvc::GatherArgs* g0, const kvc::GatherArgs* g1, hipStream_t st) {
+    kvc::GatherPair pr;
+    pr.t[0] = *g0;
+    pr.count = 1;
+    if (g1) { pr.t[1] = *g1; pr.count = 2; } else { pr.t[1] = *g0; }
+    kvc::launch_gather(pr, st);
     return hip_ok("gather launch");
 }
 
@@ -204,11 +226,19 @@ __attribute__((visibility("default"))) int kvc_scores(const kvc_params* p, const
 
 __attribute__((visibility("default"))) int kvc_select(const kvc_params* p, const void* scores, int64_t* idx_out,
                                                       void* workspace, size_t workspace_bytes, void* hip_stream) {
-    (void)workspace; (void)workspace_bytes;
     if (int rc = validate(p, false)) return rc;
     if (!scores || !idx_out) return fail(KVC_ERR_INVALID, "scores and idx_out must be non-NULL");
     if (((uintptr_t)scores) % 16 || ((uintptr_t)idx_out) % 16) return fail(KVC_ERR_ALIGNMENT, "scores / idx_out not 16-byte aligned");
-    return enqueue_select(p, scores, idx_out, static_cast<hipStream_t>(hip_stream));
+    void* scratch = nullptr;
+    if (p->tie_mode == KVC_TIES_TORCH_CPU) {
+        const size_t need = kvc::select_exact_scratch_bytes(p->bsz * p->n_q_heads, p->q_len - p->window, p->k);
+        if (need) {
+            if (!workspace || workspace_bytes < need || ((uintptr_t)workspace) % 256)
+                return fail(KVC_ERR_WORKSPACE, "kvc_select with tie_mode torch_cpu needs %zu bytes of 256-byte aligned workspace", need);
+            scratch = workspace;
+        }
+    }
+    return enqueue_select(p, scores, idx_out, nullptr, nullptr, scratch, static_cast<hipStream_t>(hip_stream));
 }
 
 __attribute__((visibility("default"))) int kvc_gather(const kvc_params* p, const void* src, int64_t stride_b, int64_t stride_h,
@@ -217,7 +247,8 @@ __attribute__((visibility("default"))) int kvc_gather(const kvc_params* p, const
     if (!src || !out) return fail(KVC_ERR_INVALID, "src and out must be non-NULL");
     if (int rc = check_strides("src", esize_of(p->dtype), stride_b, stride_h, stride_l, src)) return rc;
     if (((uintptr_t)out) % 16) return fail(KVC_ERR_ALIGNMENT, "out not 16-byte aligned");
-    return enqueue_gather(p, src, stride_b, stride_h, stride_l, idx, out, static_cast<hipStream_t>(hip_stream));
+    const kvc::GatherArgs g = gather_args(p, src, stride_b, stride_h, stride_l, idx, out);
+    return enqueue_gather(&g, nullptr, static_cast<hipStream_t>(hip_stream));
 }
 
 __attribute__((visibility("default"))) int kvc_compress(const kvc_params* p, const void* q, const void* k, const void* v,
@@ -231,7 +262,8 @@ __attribute__((visibility("default"))) int kvc_compress(const kvc_params* p, con
     if (int rc = check_strides("v", es, p->v_stride_b, p->v_stride_h, p->v_stride_l, v)) return rc;
     if (((uintptr_t)k_out) % 16 || ((uintptr_t)v_out) % 16) return fail(KVC_ERR_ALIGNMENT, "k_out / v_out not 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    const int64_t* idx = nullptr;
+    kvc::GatherArgs gk = gather_args(p, k, p->k_stride_b, p->k_stride_h, p->k_stride_l, nullptr, k_out);
+    kvc::GatherArgs gv = gather_args(p, v, p->v_stride_b, p->v_stride_h, p->v_stride_l, nullptr, v_out);
     if (scoring(p->method)) {
         if (!q) return fail(KVC_ERR_INVALID, "q must be non-NULL for scoring methods");
         if (int rc = check_strides("q", es, p->q_stride_b, p->q_stride_h, p->q_stride_l, q)) return rc;
@@ -243,13 +275,14 @@ __attribute__((visibility("default"))) int kvc_compress(const kvc_params* p, con
         void* sc = scores_out ? scores_out : static_cast<void*>(ws + l.scores);
         int64_t* ix = idx_out ? idx_out : reinterpret_cast<int64_t*>(ws + l.idx);
         if (int rc = enqueue_scores(p, l, q, k, sc, ws, st)) return rc;
-        if (int rc = enqueue_select(p, sc, ix, st)) return rc;
-        idx = ix;
+        const bool fuse = p->k > 0 && p->k <= kvc::kFuseGatherMaxK && p->tie_mode == KVC_TIES_CANONICAL;
+        if (int rc = enqueue_select(p, sc, ix, fuse ? &gk : nullptr, fuse ? &gv : nullptr, ws + l.exact, st)) return rc;
+        if (fuse) return KVC_OK;
+        gk.idx = gv.idx = ix;
     } else if (idx_out && p->k > 0) {
         return fail(KVC_ERR_UNSUPPORTED, "StreamingLLM: idx_out must be NULL (indices are arange(k), pyramidkv_utils.py:607)");
     }
-    if (int rc = enqueue_gather(p, k, p->k_stride_b, p->k_stride_h, p->k_stride_l, idx, k_out, st)) return rc;
-    return enqueue_gather(p, v, p->v_stride_b, p->v_stride_h, p->v_stride_l, idx, v_out, st);
+    return enqueue_gather(&gk, &gv, st);
 }
 
 }  // extern "C"

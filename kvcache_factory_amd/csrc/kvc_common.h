@@ -38,6 +38,10 @@ template <> struct Dt<KVC_FP16> {
         return (float)h;
     }
     __device__ static __forceinline__ raw st(float f) {   // v_cvt_f16_f32: RNE, overflow -> inf
+        // The fp32 value must exist as such before the conversion: without this barrier the compiler folds
+        // `(half)(a * b)` into v_fma_mixlo_f16, which rounds the exact product ONCE to fp16 — not the reference's
+        // round-to-fp32-then-to-fp16 (seen as 1-ulp differences on fp16-subnormal probabilities at L = 8000).
+        asm volatile("" : "+v"(f));
         _Float16 h = (_Float16)f;
         raw r;
         __builtin_memcpy(&r, &h, 2);

@@ -7,7 +7,8 @@
 
 namespace kvc {
 
-__global__ __launch_bounds__(256) void gather_kernel(const GatherArgs a) {
+__global__ __launch_bounds__(256) void gather_kernel(const GatherPair pr) {
+    const GatherArgs& a = pr.t[blockIdx.z];
     const int lanes_per_row = a.row_bytes >> 4;
     const int rows_per_block = 256 / lanes_per_row;
     const int r = threadIdx.x / lanes_per_row, c = threadIdx.x % lanes_per_row;
@@ -25,12 +26,13 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherArgs a) {
     *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
 }
 
-int launch_gather(const GatherArgs& a, hipStream_t st) {
+int launch_gather(const GatherPair& p, hipStream_t st) {
+    const GatherArgs& a = p.t[0];
     const int lanes_per_row = a.row_bytes / 16;
     const int rows_per_block = 256 / lanes_per_row;
     const int cap = a.k + a.window;
-    dim3 grid((unsigned)((cap + rows_per_block - 1) / rows_per_block), (unsigned)(a.bsz * a.n_q_heads));
-    hipLaunchKernelGGL(gather_kernel, grid, dim3(256), 0, st, a);
+    dim3 grid((unsigned)((cap + rows_per_block - 1) / rows_per_block), (unsigned)(a.bsz * a.n_q_heads), (unsigned)p.count);
+    hipLaunchKernelGGL(gather_kernel, grid, dim3(256), 0, st, p);
     return 0;
 }
 

@@ -21,22 +21,29 @@ struct ScoreArgs {
     float sqrt_d;
 };
 
-struct SelectArgs {
-    const void* scores;    // [bsz*Hq][n] dtype
-    int64_t* idx;          // [bsz*Hq][k]
-    int n, k, heads;       // heads = bsz*Hq
-    int pow2;              // next power of two >= k
-};
-
 struct GatherArgs {
     const void* src; void* out; const int64_t* idx;   // idx may be null (identity)
     int64_t stride_b, stride_h, stride_l;             // elements
     int bsz, n_q_heads, group, q_len, window, k, row_bytes, esize;
 };
 
+struct SelectArgs {
+    const void* scores;    // [bsz*Hq][n] dtype
+    int64_t* idx;          // [bsz*Hq][k]
+    int n, k, heads;       // heads = bsz*Hq
+    int pow2;              // next power of two >= k
+    int fuse;              // 1: also gather K (gk) and V (gv) rows of the head in the same workgroup
+    GatherArgs gk, gv;
+};
+
+struct GatherPair { GatherArgs t[2]; int count; };    // K and V compacted by one launch
+
 int launch_scores(const ScoreArgs& a, int dtype, int head_dim, hipStream_t st);
 int launch_select(const SelectArgs& a, int dtype, int tie_mode, hipStream_t st);
 size_t select_lds_bytes(int k);
-int launch_gather(const GatherArgs& a, hipStream_t st);
+int launch_select_exact(const SelectArgs& a, int dtype, void* scratch, hipStream_t st);   // tie_mode torch_cpu
+size_t select_exact_scratch_bytes(int heads, int n, int k);
+int launch_gather(const GatherPair& p, hipStream_t st);
+static constexpr int kFuseGatherMaxK = 512;   // select_kernel gathers the rows itself up to this k
 
 }  // namespace kvc

@@ -44,7 +44,7 @@ template <> __device__ __forceinline__ float pick<KVC_FP32>(const uint4& v, int 
 // grid  = (ceil(L/128), bsz * n_kv_heads), block = 256 (4 waves x 32 keys)
 // LDS   = 128 * D * esize (K tile) + 4*32*4 (per-wave row maxima)
 // ---------------------------------------------------------------------------------------------
-template <int DT, int D>
+template <int DT, int D, int WV>
 __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
     typedef typename Dt<DT>::raw raw;
     constexpr int ES = Dt<DT>::esize;
@@ -58,8 +58,21 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
     const int tile = blockIdx.x;
     const int b = blockIdx.y / a.n_kv_heads, g = blockIdx.y % a.n_kv_heads;
-    const int L = a.q_len, W = a.window, G = a.group;
+    const int L = a.q_len, W = WV > 0 ? WV : a.window, G = a.group;
     const int key0 = tile * 128;
+    const int rows = G * W;                   // query rows sharing this KV head
+    const int n_mt = (rows + 31) / 32;
+
+    // ---- first M-tile's query row: issue the loads now, convert after the K tile is staged ----
+    uint4 qraw[CH];
+    {
+        const bool valid = j < rows;
+        const int hq = g * G + (valid ? j / W : 0), w = valid ? j % W : 0;
+        const char* qrow = reinterpret_cast<const char*>(a.q) +
+            ((int64_t)b * a.q_stride_b + (int64_t)hq * a.q_stride_h + (int64_t)(L - W + w) * a.q_stride_l) * ES;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) qraw[c] = valid ? *reinterpret_cast<const uint4*>(qrow + c * 16) : make_uint4(0, 0, 0, 0);
+    }
 
     // ---- stage the K tile: 128 rows x CH chunks, coalesced, swizzled ----
     const char* kbase = reinterpret_cast<const char*>(a.k) +
@@ -73,8 +86,6 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
     }
     __syncthreads();
 
-    const int rows = G * W;                   // query rows sharing this KV head
-    const int n_mt = (rows + 31) / 32;
     const int key = key0 + wave * 32 + j;
     const float sqrt_d = a.sqrt_d;
     const char* krow = smem + (wave * 32 + j) * ROWB;
@@ -82,19 +93,19 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
     for (int mt = 0; mt < n_mt; ++mt) {
         // ---- A operand: this lane's query row, its parity's elements, as fp32 ----
         float areg[D / 2];
-        {
+        if (mt > 0) {
             const int i = mt * 32 + j;
             const bool valid = i < rows;
             const int hq = g * G + (valid ? i / W : 0), w = valid ? i % W : 0;
             const char* qrow = reinterpret_cast<const char*>(a.q) +
                 ((int64_t)b * a.q_stride_b + (int64_t)hq * a.q_stride_h + (int64_t)(L - W + w) * a.q_stride_l) * ES;
 #pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (valid) v = *reinterpret_cast<const uint4*>(qrow + c * 16);
+            for (int c = 0; c < CH; ++c) qraw[c] = valid ? *reinterpret_cast<const uint4*>(qrow + c * 16) : make_uint4(0, 0, 0, 0);
+        }
 #pragma unroll
-                for (int s = 0; s < PAIRS; ++s) areg[c * PAIRS + s] = pick<DT>(v, s, kh);
-            }
+        for (int c = 0; c < CH; ++c) {
+#pragma unroll
+            for (int s = 0; s < PAIRS; ++s) areg[c * PAIRS + s] = pick<DT>(qraw[c], s, kh);
         }
         // ---- 32 rows x 32 keys, chain over d = 0..D-1 in order ----
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -106,22 +117,22 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c * PAIRS + s], pick<DT>(kv, s, kh), acc, 0, 0, 0);
         }
         // ---- epilogue: 3 roundings, mask, store [h][key][w], tile row maxima ----
+        float xs[16];
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             float x[4];
             const int i0 = mt * 32 + 8 * rg + 4 * kh;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int i = i0 + e;
-                const int w = i % W;
+                const int w = (i0 + e) % W;
                 float v = rnd<DT>(acc[rg * 4 + e]);
                 v = rnd<DT>(v / sqrt_d);
                 if (key >= L - W && (key - (L - W)) > w) v = rnd<DT>(v + Dt<DT>::finfo_min());
                 x[e] = v;
+                xs[rg * 4 + e] = (key < L) ? v : -__builtin_inff();
             }
-            const bool vec_ok = (W % 4) == 0;
             if (i0 < rows && key < L) {
-                if (vec_ok) {
+                if ((W % 4) == 0) {
                     const int hq = g * G + i0 / W, w0 = i0 % W;
                     raw* dst = reinterpret_cast<raw*>(a.logits) + (((int64_t)b * a.n_q_heads + hq) * L + key) * W + w0;
                     if constexpr (ES == 2) {
@@ -143,13 +154,35 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
                     }
                 }
             }
-            // per-row maximum over this wave's 32 keys
+        }
+        // per-row maximum over this wave's 32 keys: reduce-scatter over the 5 key bits (16 cross-lane moves):
+        // after the step on lane bit t, each lane keeps only the registers whose index bit matches its own.
+        {
+            const bool b4 = (j & 16) != 0, b3 = (j & 8) != 0, b2 = (j & 4) != 0, b1 = (j & 2) != 0;
+            float y[8], z[4], u[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float m = (key < L) ? x[e] : -__builtin_inff();
-                m = half_xor_max(m);
-                if (j == 0) wmax[wave * 32 + 8 * rg + 4 * kh + e] = m;
+            for (int r = 0; r < 8; ++r) {
+                const float o = __shfl_xor(b4 ? xs[r] : xs[r + 8], 16);
+                const float keep = b4 ? xs[r + 8] : xs[r];
+                y[r] = o > keep ? o : keep;
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float o = __shfl_xor(b3 ? y[r] : y[r + 4], 8);
+                const float keep = b3 ? y[r + 4] : y[r];
+                z[r] = o > keep ? o : keep;
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float o = __shfl_xor(b2 ? z[r] : z[r + 2], 4);
+                const float keep = b2 ? z[r + 2] : z[r];
+                u[r] = o > keep ? o : keep;
+            }
+            float m = __shfl_xor(b1 ? u[0] : u[1], 2);
+            { const float keep = b1 ? u[1] : u[0]; m = m > keep ? m : keep; }
+            { const float o = __shfl_xor(m, 1); m = o > m ? o : m; }
+            const int R = (b1 ? 1 : 0) + (b2 ? 2 : 0) + (b3 ? 4 : 0) + (b4 ? 8 : 0);     // accumulator register index
+            if ((j & 1) == 0) wmax[wave * 32 + (R & 3) + 8 * (R >> 2) + 4 * kh] = m;
         }
         __syncthreads();
         if (tid < 32) {
@@ -261,15 +294,24 @@ __global__ __launch_bounds__(256) void pool_kernel(const ScoreArgs a) {
     const int pad = a.pooling == KVC_POOL_NONE ? 0 : a.kernel_size / 2;
     const int j0 = blockIdx.x * 256;
 
-    if (tid < W) {
-        m[tid] = a.rowmax[(int64_t)hb * W + tid];
-        float s = 0.0f;
-        for (int c = 0; c < a.n_chunks; ++c) {
-            const float v = a.psum[((int64_t)hb * a.n_chunks + c) * W + tid];
-            s = c == 0 ? v : s + v;
+    // row sums: chunk partials are fetched by all threads (coalesced), then added left to right per row
+    {
+        float* stage = s_tile;                               // reuse: (256 + 64) floats per round
+        float run = 0.0f;
+        const int per_round = 320 / W;                       // chunks per round
+        for (int c0 = 0; c0 < a.n_chunks; c0 += per_round) {
+            const int cn = a.n_chunks - c0 < per_round ? a.n_chunks - c0 : per_round;
+            for (int t = tid; t < cn * W; t += 256) stage[t] = a.psum[((int64_t)hb * a.n_chunks + c0) * W + t];
+            __syncthreads();
+            if (tid < W)
+                for (int c = 0; c < cn; ++c) { const float v = stage[c * W + tid]; run = (c0 + c) == 0 ? v : run + v; }
+            __syncthreads();
         }
-        rinv[tid] = 1.0f / s;
-        if (blockIdx.x == 0) a.rowsum[(int64_t)hb * W + tid] = s;
+        if (tid < W) {
+            m[tid] = a.rowmax[(int64_t)hb * W + tid];
+            rinv[tid] = 1.0f / run;
+            if (blockIdx.x == 0) a.rowsum[(int64_t)hb * W + tid] = run;
+        }
     }
     __syncthreads();
 
@@ -326,18 +368,23 @@ static void launch_softmax_pool_t(const ScoreArgs& a, hipStream_t st) {
     if (m & 4) hipLaunchKernelGGL((pool_kernel<DT, WV>), g3, dim3(256), 0, st, a);
 }
 
-template <int DT, int D>
-static int launch_scores_t(const ScoreArgs& a, hipStream_t st) {
+template <int DT, int D, int WV>
+static void launch_all_t(const ScoreArgs& a, hipStream_t st) {
     constexpr int ES = Dt<DT>::esize;
     const size_t lds = (size_t)128 * D * ES + 4 * 32 * sizeof(float);
     dim3 g1((unsigned)a.n_tiles, (unsigned)(a.bsz * a.n_kv_heads));
-    if ((a.stage_mask ? a.stage_mask : 7) & 1) hipLaunchKernelGGL((logits_kernel<DT, D>), g1, dim3(256), lds, st, a);
+    if ((a.stage_mask ? a.stage_mask : 7) & 1) hipLaunchKernelGGL((logits_kernel<DT, D, WV>), g1, dim3(256), lds, st, a);
+    launch_softmax_pool_t<DT, WV>(a, st);
+}
+
+template <int DT, int D>
+static int launch_scores_t(const ScoreArgs& a, hipStream_t st) {
     switch (a.window) {
-        case 8:  launch_softmax_pool_t<DT, 8>(a, st); break;
-        case 16: launch_softmax_pool_t<DT, 16>(a, st); break;
-        case 32: launch_softmax_pool_t<DT, 32>(a, st); break;
-        case 64: launch_softmax_pool_t<DT, 64>(a, st); break;
-        default: launch_softmax_pool_t<DT, 0>(a, st); break;
+        case 8:  launch_all_t<DT, D, 8>(a, st); break;
+        case 16: launch_all_t<DT, D, 16>(a, st); break;
+        case 32: launch_all_t<DT, D, 32>(a, st); break;
+        case 64: launch_all_t<DT, D, 64>(a, st); break;
+        default: launch_all_t<DT, D, 0>(a, st); break;
     }
     return 0;
 }

@@ -1,14 +1,17 @@
 // kvc_select.hip — A7: per-head top-k of the pooled scores (pyramidkv_utils.py:334,
-// `attn_cache.topk(k, dim=-1).indices`) on gfx950.
+// `attn_cache.topk(k, dim=-1).indices`) on gfx950, optionally followed in the same workgroup by A8 (the
+// gather of that head's K/V rows) when k is small.
 //
-// select_canon_kernel (tie_mode KVC_TIES_CANONICAL): one 1024-thread workgroup per head.
-//   1. MSB-first radix select over order-preserving integer keys (16-bit keys for bf16/fp16 scores:
-//      two 8-bit passes; 32-bit keys for fp32: four) -> threshold key T and r = how many of the
-//      candidates equal to T are needed;
-//   2. one ordered sweep: every key > T plus the r lowest-index keys == T go to an LDS list as
-//      (inverted key << 32 | index);
-//   3. bitonic sort of the list in LDS -> value descending, index ascending; written as int64.
-// The scores of a head (n * 2 bytes) are read three times from L2; nothing else touches HBM.
+// select_kernel: one 1024-thread workgroup per head, the head's scores held in registers as
+// order-preserving integer keys (thread t owns candidates [t*EPT, (t+1)*EPT)).
+//   1. threshold: bit-by-bit search of the k-th largest key T (one block-wide count per key bit:
+//      16 rounds for bf16/fp16, 32 for fp32) — no atomics, no histogram contention on the few hundred
+//      distinct values a head really has;
+//   2. membership: every key > T, plus the r = k - count(key > T) candidates equal to T chosen by tie_mode:
+//        KVC_TIES_CANONICAL  lowest index first (ordered block scan);
+//   3. order: value descending, index ascending (rank sort in LDS for k <= 256, bitonic sort otherwise);
+//   4. (fused) gather of the head's k + W rows of K and V straight from the sorted LDS list.
+// The scores of a head (n * 2 bytes) are read once from L2; nothing else touches HBM except the rows.
 #include "kvc_common.h"
 #include "kvc_launch.h"
 
@@ -16,123 +19,185 @@ namespace kvc {
 
 static constexpr int SEL_THREADS = 1024;
 static constexpr int SEL_WAVES = SEL_THREADS / 64;
+static constexpr int SEL_MAX_EPT = 64;          // n <= 65536 candidates per head
 
 size_t select_lds_bytes(int k) {
     int p = 1;
     while (p < k) p <<= 1;
-    return (size_t)p * 8 + (256 + 256 + 16 + SEL_WAVES) * 4;
+    return (size_t)p * 8 + 64 * 4;
 }
 
-template <int DT>
-__global__ __launch_bounds__(SEL_THREADS) void select_canon_kernel(const SelectArgs a) {
+// Sum of one small per-thread count over the block; result broadcast to every thread.
+// `slot` alternates between two LDS arrays so that one barrier per call is enough.
+__device__ __forceinline__ uint32_t block_sum(uint32_t wave_total, uint32_t* buf /*[2][SEL_WAVES]*/, int slot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) buf[slot * SEL_WAVES + wave] = wave_total;
+    __syncthreads();
+    uint32_t s = 0;
+#pragma unroll
+    for (int w = 0; w < SEL_WAVES; ++w) s += buf[slot * SEL_WAVES + w];
+    return s;
+}
+
+// Exclusive prefix (in thread order) of a per-thread count, plus the block total.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* buf, int slot, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) buf[slot * SEL_WAVES + wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SEL_WAVES; ++w) { const uint32_t c = buf[slot * SEL_WAVES + w]; if (w < wave) base += c; tot += c; }
+    *total = tot;
+    return base + inc - v;
+}
+
+template <int DT, int EPT>
+__global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a) {
     typedef typename Dt<DT>::raw raw;
     constexpr int KB = Key<DT>::bits;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long* list = reinterpret_cast<unsigned long long*>(smem);
-    uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (size_t)a.pow2 * 8);   // [256]
-    uint32_t* scan = hist + 256;                                               // [256]
-    uint32_t* misc = scan + 256;                                               // [16]
-    uint32_t* wcnt = misc + 16;                                                // [SEL_WAVES]
+    unsigned long long* list = reinterpret_cast<unsigned long long*>(smem);      // [pow2]
+    uint32_t* buf = reinterpret_cast<uint32_t*>(smem + (size_t)a.pow2 * 8);      // [2][SEL_WAVES] + spare
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int n = a.n, k = a.k;
-    const raw* s = reinterpret_cast<const raw*>(a.scores) + (int64_t)blockIdx.x * n;
+    const int head = blockIdx.x;
+    const raw* s = reinterpret_cast<const raw*>(a.scores) + (int64_t)head * n;
 
-    // ---- 1. radix select of the k-th largest key ----
-    uint32_t prefix = 0;
-    uint32_t k_rem = (uint32_t)k;
-    for (int shift = KB - 8; shift >= 0; shift -= 8) {
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
-        for (int i = tid; i < n; i += SEL_THREADS) {
-            const uint32_t key = Key<DT>::of(s[i]);
-            if (shift + 8 == KB || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        // inclusive suffix sums: scan[d] = sum_{d' >= d} hist[d']
-        if (tid < 256) scan[tid] = hist[tid];
-        __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
-            uint32_t v = 0;
-            if (tid < 256) v = scan[tid] + (tid + off < 256 ? scan[tid + off] : 0u);
-            __syncthreads();
-            if (tid < 256) scan[tid] = v;
-            __syncthreads();
-        }
-        if (tid < 256) {
-            const uint32_t ge = scan[tid], gt = tid < 255 ? scan[tid + 1] : 0u;
-            if (ge >= k_rem && gt < k_rem) { misc[0] = (uint32_t)tid; misc[1] = k_rem - gt; }
-        }
-        __syncthreads();
-        prefix = (prefix << 8) | misc[0];
-        k_rem = misc[1];
-        __syncthreads();
-    }
-    const uint32_t T = prefix, r = k_rem;
-
-    // ---- 2. ordered sweep: keys > T, and the r first keys == T ----
-    if (tid == 0) misc[2] = 0;
-    __syncthreads();
-    uint32_t eq_base = 0;
-    for (int base = 0; base < n; base += SEL_THREADS) {
-        const int i = base + tid;
-        uint32_t key = 0;
-        bool gt = false, eq = false;
-        if (i < n) { key = Key<DT>::of(s[i]); gt = key > T; eq = key == T; }
-        const unsigned long long bal = __ballot(eq);
-        const uint32_t lane_prefix = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wcnt[wave] = (uint32_t)__popcll(bal);
-        __syncthreads();
-        uint32_t wave_off = 0, total = 0;
+    // ---- candidates into registers ----
+    uint32_t key[EPT];
+    const int i0 = tid * EPT;
 #pragma unroll
-        for (int w = 0; w < SEL_WAVES; ++w) { const uint32_t c = wcnt[w]; if (w < wave) wave_off += c; total += c; }
-        const bool take = gt || (eq && (eq_base + wave_off + lane_prefix) < r);
-        if (take) {
-            const uint32_t slot = atomicAdd(&misc[2], 1u);
-            list[slot] = ((unsigned long long)(0xffffffffu - key) << 32) | (uint32_t)i;
-        }
-        eq_base += total;
-        __syncthreads();
+    for (int e = 0; e < EPT; ++e) key[e] = (i0 + e < n) ? Key<DT>::of(s[i0 + e]) : 0u;
+
+    // ---- 1. threshold: largest T with count(key >= T) >= k ----
+    uint32_t T = 0;
+    int slot = 0;
+    for (int bit = KB - 1; bit >= 0; --bit) {
+        const uint32_t cand = T | (1u << bit);
+        uint32_t c = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) c += (uint32_t)__popcll(__ballot(key[e] >= cand && (i0 + e) < n));
+        if (block_sum(c, buf, slot) >= (uint32_t)k) T = cand;
+        slot ^= 1;
     }
-    for (int i = k + tid; i < a.pow2; i += SEL_THREADS) list[i] = ~0ull;
+    // ---- 2. membership ----
+    uint32_t cg = 0, ce = 0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const bool valid = (i0 + e) < n;
+        cg += (valid && key[e] > T) ? 1u : 0u;
+        ce += (valid && key[e] == T) ? 1u : 0u;
+    }
+    uint32_t tot_gt, tot_eq, tot_take;
+    (void)block_excl_scan(cg, buf, slot, &tot_gt); slot ^= 1;
+    const uint32_t r = (uint32_t)k - tot_gt;                       // ties needed (>= 1)
+    const uint32_t eq_before = block_excl_scan(ce, buf, slot, &tot_eq); slot ^= 1;
+    const uint32_t eq_take = eq_before >= r ? 0u : (r - eq_before < ce ? r - eq_before : ce);
+    uint32_t pos = block_excl_scan(cg + eq_take, buf, slot, &tot_take); slot ^= 1;
+    {
+        uint32_t eq_seen = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const bool valid = (i0 + e) < n;
+            bool take = valid && key[e] > T;
+            if (valid && key[e] == T) { take = eq_seen < eq_take; ++eq_seen; }
+            if (take) list[pos++] = ((unsigned long long)(0xffffffffu - key[e]) << 32) | (uint32_t)(i0 + e);
+        }
+    }
     __syncthreads();
 
-    // ---- 3. bitonic sort (ascending composite == value descending, index ascending) ----
-    const int P = a.pow2;
-    for (int size = 2; size <= P; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < P / 2; t += SEL_THREADS) {
-                const int lo = 2 * t - (t & (stride - 1));
-                const int hi = lo + stride;
-                const bool asc = (lo & size) == 0;
-                const unsigned long long x = list[lo], y = list[hi];
-                if ((x > y) == asc) { list[lo] = y; list[hi] = x; }
+    // ---- 3. order ----
+    int64_t* out = a.idx + (int64_t)head * k;
+    if (k <= 256) {
+        // rank sort: composites are unique, rank = number of smaller composites
+        unsigned long long mine = 0;
+        uint32_t rank = 0;
+        if (tid < k) {
+            mine = list[tid];
+            for (int u = 0; u < k; ++u) rank += list[u] < mine ? 1u : 0u;
+        }
+        __syncthreads();
+        if (tid < k) list[rank] = mine;
+        __syncthreads();
+    } else {
+        const int P = a.pow2;
+        for (int i = k + tid; i < P; i += SEL_THREADS) list[i] = ~0ull;
+        __syncthreads();
+        for (int size = 2; size <= P; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = tid; t < P / 2; t += SEL_THREADS) {
+                    const int lo = 2 * t - (t & (stride - 1));
+                    const int hi = lo + stride;
+                    const bool asc = (lo & size) == 0;
+                    const unsigned long long x = list[lo], y = list[hi];
+                    if ((x > y) == asc) { list[lo] = y; list[hi] = x; }
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
-    int64_t* out = a.idx + (int64_t)blockIdx.x * k;
     for (int t = tid; t < k; t += SEL_THREADS) out[t] = (int64_t)(list[t] & 0xffffffffull);
+
+    // ---- 4. fused gather of this head's rows (small k only) ----
+    if (a.fuse) {
+        const int lanes_per_row = a.gk.row_bytes >> 4;
+        const int rows_per_pass = SEL_THREADS / lanes_per_row;
+        const int rr = tid / lanes_per_row, cc = tid % lanes_per_row;
+        const int cap = k + a.gk.window;
+        const int b = head / a.gk.n_q_heads, h = head % a.gk.n_q_heads;
+        const int64_t esz = a.gk.esize;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const GatherArgs& g = which == 0 ? a.gk : a.gv;
+            const char* sbase = reinterpret_cast<const char*>(g.src) + ((int64_t)b * g.stride_b + (int64_t)(h / g.group) * g.stride_h) * esz;
+            char* obase = reinterpret_cast<char*>(g.out) + (int64_t)head * cap * g.row_bytes;
+            for (int t0 = 0; t0 < cap; t0 += rows_per_pass) {
+                const int t = t0 + rr;
+                if (rr < rows_per_pass && t < cap) {
+                    const int64_t srow = t < k ? (int64_t)(list[t] & 0xffffffffull) : (int64_t)(g.q_len - g.window) + (t - k);
+                    *reinterpret_cast<uint4*>(obase + (int64_t)t * g.row_bytes + cc * 16) =
+                        *reinterpret_cast<const uint4*>(sbase + srow * g.stride_l * esz + cc * 16);
+                }
+            }
+        }
+    }
 }
 
-template <int DT>
-static int launch_canon(const SelectArgs& a, hipStream_t st) {
+template <int DT, int EPT>
+static int launch_t(const SelectArgs& a, hipStream_t st) {
     const size_t lds = select_lds_bytes(a.k);
     if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&select_canon_kernel<DT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&select_kernel<DT, EPT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return KVC_ERR_HIP;
     }
-    hipLaunchKernelGGL((select_canon_kernel<DT>), dim3((unsigned)a.heads), dim3(SEL_THREADS), lds, st, a);
+    hipLaunchKernelGGL((select_kernel<DT, EPT>), dim3((unsigned)a.heads), dim3(SEL_THREADS), lds, st, a);
     return 0;
+}
+
+template <int DT>
+static int launch_dt(const SelectArgs& a, hipStream_t st) {
+    const int ept = (a.n + SEL_THREADS - 1) / SEL_THREADS;
+    if (ept <= 8) return launch_t<DT, 8>(a, st);
+    if (ept <= 16) return launch_t<DT, 16>(a, st);
+    if (ept <= 32) return launch_t<DT, 32>(a, st);
+    if (ept <= SEL_MAX_EPT) return launch_t<DT, SEL_MAX_EPT>(a, st);
+    return KVC_ERR_UNSUPPORTED;
 }
 
 int launch_select(const SelectArgs& a, int dtype, int tie_mode, hipStream_t st) {
     if (tie_mode != KVC_TIES_CANONICAL) return KVC_ERR_UNSUPPORTED;
     switch (dtype) {
-        case KVC_BF16: return launch_canon<KVC_BF16>(a, st);
-        case KVC_FP16: return launch_canon<KVC_FP16>(a, st);
-        case KVC_FP32: return launch_canon<KVC_FP32>(a, st);
+        case KVC_BF16: return launch_dt<KVC_BF16>(a, st);
+        case KVC_FP16: return launch_dt<KVC_FP16>(a, st);
+        case KVC_FP32: return launch_dt<KVC_FP32>(a, st);
     }
     return KVC_ERR_INVALID;
 }

@@ -1,0 +1,194 @@
+// kvc_stl_emul.h — the libstdc++ algorithms torch-CPU topk runs (std::partial_sort; std::nth_element + std::sort),
+// restated move for move on (key << 32 | index) elements so that ties resolve exactly as they do there.
+// Sources restated: GCC 11 bits/stl_heap.h (__push_heap, __adjust_heap, __make_heap, __sort_heap) and bits/stl_algo.h
+// (__heap_select, __move_median_to_first, __unguarded_partition(_pivot), __introselect, __insertion_sort,
+// __unguarded_linear_insert, __introsort_loop, __final_insertion_sort).  Compiles for the device (hipcc) and for the
+// host (g++, used by tests/test_stl_emul.py to check it against the real library on tie-heavy inputs).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define KVC_HD __device__
+#else
+#define KVC_HD
+#endif
+
+namespace kvc {
+
+typedef unsigned long long u64;
+
+#if defined(__HIPCC__)
+// every lane of the wave runs the same program: make loaded values wave-uniform so branches are scalar
+KVC_HD inline u64 uni(u64 v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+KVC_HD inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#else
+inline u64 uni(u64 v) { return v; }
+inline int uni(int v) { return v; }
+#endif
+
+// comp(a, b): a sorts before b  <=>  value(a) > value(b)   (NaN-free scores; keys are order-preserving)
+KVC_HD inline bool comp(u64 a, u64 b) { return (uint32_t)(a >> 32) > (uint32_t)(b >> 32); }
+
+struct Arr {                 // random-access view of the (key<<32 | index) array, LDS or global
+    u64* p;
+    KVC_HD inline u64 get(int i) const { return uni(p[i]); }
+    KVC_HD inline void set(int i, u64 v) const { p[i] = v; }
+    KVC_HD inline void swap(int i, int j) const { const u64 a = get(i), b = get(j); p[i] = b; p[j] = a; }
+};
+
+// ---- libstdc++ bits/stl_heap.h ----------------------------------------------------------------------------
+KVC_HD inline void push_heap_(const Arr& A, int first, int hole, int top, u64 value) {
+    int parent = (hole - 1) / 2;
+    while (hole > top && comp(A.get(first + parent), value)) {
+        A.set(first + hole, A.get(first + parent));
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    A.set(first + hole, value);
+}
+KVC_HD inline void adjust_heap_(const Arr& A, int first, int hole, int len, u64 value) {
+    const int top = hole;
+    int second = hole;
+    while (second < (len - 1) / 2) {
+        second = 2 * (second + 1);
+        if (comp(A.get(first + second), A.get(first + second - 1))) second--;
+        A.set(first + hole, A.get(first + second));
+        hole = second;
+    }
+    if ((len & 1) == 0 && second == (len - 2) / 2) {
+        second = 2 * (second + 1);
+        A.set(first + hole, A.get(first + second - 1));
+        hole = second - 1;
+    }
+    push_heap_(A, first, hole, top, value);
+}
+KVC_HD inline void make_heap_(const Arr& A, int first, int last) {
+    const int len = last - first;
+    if (len < 2) return;
+    int parent = (len - 2) / 2;
+    while (true) {
+        const u64 value = A.get(first + parent);
+        adjust_heap_(A, first, parent, len, value);
+        if (parent == 0) return;
+        parent--;
+    }
+}
+KVC_HD inline void sort_heap_(const Arr& A, int first, int last) {
+    while (last - first > 1) {
+        --last;
+        const u64 value = A.get(last);
+        A.set(last, A.get(first));
+        adjust_heap_(A, first, 0, last - first, value);
+    }
+}
+// heap_select over an array that is fully materialised in A
+KVC_HD inline void heap_select_(const Arr& A, int first, int middle, int last) {
+    make_heap_(A, first, middle);
+    for (int i = middle; i < last; ++i) {
+        const u64 vi = A.get(i);
+        if (comp(vi, A.get(first))) {
+            A.set(i, A.get(first));
+            adjust_heap_(A, first, 0, middle - first, vi);
+        }
+    }
+}
+
+// ---- libstdc++ bits/stl_algo.h ----------------------------------------------------------------------------
+KVC_HD inline int lg_(int n) { return 31 - __builtin_clz(n); }
+
+KVC_HD inline void move_median_to_first_(const Arr& A, int result, int a, int b, int c) {
+    const u64 va = A.get(a), vb = A.get(b), vc = A.get(c);
+    if (comp(va, vb)) {
+        if (comp(vb, vc)) A.swap(result, b);
+        else if (comp(va, vc)) A.swap(result, c);
+        else A.swap(result, a);
+    } else if (comp(va, vc)) A.swap(result, a);
+    else if (comp(vb, vc)) A.swap(result, c);
+    else A.swap(result, b);
+}
+KVC_HD inline int unguarded_partition_(const Arr& A, int first, int last, int pivot) {
+    const u64 pv = A.get(pivot);
+    while (true) {
+        while (comp(A.get(first), pv)) ++first;
+        --last;
+        while (comp(pv, A.get(last))) --last;
+        if (!(first < last)) return first;
+        A.swap(first, last);
+        ++first;
+    }
+}
+KVC_HD inline int unguarded_partition_pivot_(const Arr& A, int first, int last) {
+    const int mid = first + (last - first) / 2;
+    move_median_to_first_(A, first, first + 1, mid, last - 1);
+    return unguarded_partition_(A, first + 1, last, first);
+}
+KVC_HD inline void unguarded_linear_insert_(const Arr& A, int last) {
+    const u64 val = A.get(last);
+    int next = last - 1;
+    while (comp(val, A.get(next))) {
+        A.set(last, A.get(next));
+        last = next;
+        --next;
+    }
+    A.set(last, val);
+}
+KVC_HD inline void insertion_sort_(const Arr& A, int first, int last) {
+    if (first == last) return;
+    for (int i = first + 1; i != last; ++i) {
+        const u64 vi = A.get(i);
+        if (comp(vi, A.get(first))) {
+            for (int j = i; j > first; --j) A.set(j, A.get(j - 1));     // move_backward(first, i, i + 1)
+            A.set(first, vi);
+        } else {
+            unguarded_linear_insert_(A, i);
+        }
+    }
+}
+KVC_HD inline void introselect_(const Arr& A, int first, int nth, int last, int depth_limit) {
+    while (last - first > 3) {
+        if (depth_limit == 0) {
+            heap_select_(A, first, nth + 1, last);
+            A.swap(first, nth);
+            return;
+        }
+        --depth_limit;
+        const int cut = unguarded_partition_pivot_(A, first, last);
+        if (cut <= nth) first = cut; else last = cut;
+    }
+    insertion_sort_(A, first, last);
+}
+// std::sort = introsort loop (explicit stack instead of recursion) + final insertion sort
+KVC_HD inline void sort_(const Arr& A, int first, int last, int* stack /*LDS, 3 ints per frame, >= 64 frames*/) {
+    if (first == last) return;
+    int sp = 0;
+    int f = first, l = last, d = lg_(last - first) * 2;
+    while (true) {
+        while (l - f > 16) {
+            if (d == 0) {                       // __partial_sort(first, last, last): heap sort of the range
+                heap_select_(A, f, l, l);
+                sort_heap_(A, f, l);
+                break;
+            }
+            --d;
+            const int cut = unguarded_partition_pivot_(A, f, l);
+            // recurse on [cut, l) first (libstdc++ order), then continue with [f, cut): ranges are disjoint, so
+            // deferring the right part on a stack yields the same final array.
+            stack[3 * sp] = cut; stack[3 * sp + 1] = l; stack[3 * sp + 2] = d; ++sp;
+            l = cut;
+        }
+        if (sp == 0) break;
+        --sp;
+        f = uni(stack[3 * sp]); l = uni(stack[3 * sp + 1]); d = uni(stack[3 * sp + 2]);
+    }
+    if (last - first > 16) {
+        insertion_sort_(A, first, first + 16);
+        for (int i = first + 16; i != last; ++i) unguarded_linear_insert_(A, i);
+    } else {
+        insertion_sort_(A, first, last);
+    }
+}
+
+}  // namespace kvc
