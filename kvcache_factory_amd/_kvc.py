@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkvc_hip.so")
+LIB_PATH = os.environ.get("KVC_LIB_PATH", os.path.join(_HERE, "libkvc_hip.so"))   # override only for diagnostic builds
 
 SNAPKV, PYRAMIDKV, H2O, STREAMINGLLM = 0, 1, 2, 3
 BF16, FP16, FP32 = 0, 1, 2

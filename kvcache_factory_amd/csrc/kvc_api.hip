@@ -25,7 +25,7 @@ inline int esize_of(int dtype) { return dtype == KVC_FP32 ? 4 : 2; }
 inline bool scoring(int method) { return method == KVC_SNAPKV || method == KVC_PYRAMIDKV || method == KVC_H2O; }
 
 struct Layout {
-    size_t logits, pmax, psum, rowmax, rowsum, scores, idx, exact, total;
+    size_t logits, pmax, psum, rowmax, rowsum, scores, idx, exact, total;   // H2O: logits = S [L][L], rowmax/rowsum = [L] per head
     int n_tiles, n_chunks;
 };
 
@@ -71,15 +71,24 @@ Layout carve(const kvc_params* p) {
     std::memset(&l, 0, sizeof(l));
     const size_t es = (size_t)esize_of(p->dtype);
     const size_t heads = (size_t)p->bsz * p->n_q_heads, L = (size_t)p->q_len, W = (size_t)p->window, n = L - W;
-    l.n_tiles = (int)((L + 127) / 128);
+    // logits_kernel: 4 waves per workgroup, each wave walks 32-key tiles; aim at ~2048 waves on the chip
+    {
+        const int tiles32 = (int)((L + 31) / 32);
+        const int kvh = p->bsz * p->n_kv_heads;
+        int waves = 2048 / (kvh > 0 ? kvh : 1);
+        if (waves < 4) waves = 4;
+        if (waves > tiles32) waves = tiles32;
+        l.n_tiles = (waves + 3) / 4;                       // workgroups per KV head == tile maxima per row
+    }
     l.n_chunks = (int)((L + 255) / 256);
     size_t off = 0;
     if (scoring(p->method)) {
-        l.logits = off; off = align_up(off + heads * L * W * es, 256);
-        l.pmax = off;   off = align_up(off + heads * (size_t)l.n_tiles * W * 4, 256);
-        l.psum = off;   off = align_up(off + heads * (size_t)l.n_chunks * W * 4, 256);
-        l.rowmax = off; off = align_up(off + heads * W * 4, 256);
-        l.rowsum = off; off = align_up(off + heads * W * 4, 256);
+        const size_t R = p->method == KVC_H2O ? L : W;     // query rows that score
+        l.logits = off; off = align_up(off + heads * L * R * es, 256);
+        l.pmax = off;   off = align_up(off + (p->method == KVC_H2O ? 0 : heads * (size_t)l.n_tiles * W * 4), 256);
+        l.psum = off;   off = align_up(off + (p->method == KVC_H2O ? 0 : heads * (size_t)l.n_chunks * W * 4), 256);
+        l.rowmax = off; off = align_up(off + heads * R * 4, 256);
+        l.rowsum = off; off = align_up(off + heads * R * 4, 256);
         l.scores = off; off = align_up(off + heads * n * es, 256);
         l.idx = off;    off = align_up(off + heads * (size_t)p->k * 8, 256);
         l.exact = off;
@@ -105,7 +114,22 @@ int hip_ok(const char* where) {
 }
 
 int enqueue_scores(const kvc_params* p, const Layout& l, const void* q, const void* k, void* scores, char* ws, hipStream_t st) {
-    if (p->method == KVC_H2O) return fail(KVC_ERR_UNSUPPORTED, "H2O scoring kernel not built yet");
+    if (p->method == KVC_H2O) {
+        kvc::H2OArgs h;
+        h.q = q; h.k = k;
+        h.S = ws + l.logits;
+        h.rowmax = reinterpret_cast<float*>(ws + l.rowmax);
+        h.rinv = reinterpret_cast<float*>(ws + l.rowsum);
+        h.scores = scores;
+        h.q_stride_b = p->q_stride_b; h.q_stride_h = p->q_stride_h; h.q_stride_l = p->q_stride_l;
+        h.k_stride_b = p->k_stride_b; h.k_stride_h = p->k_stride_h; h.k_stride_l = p->k_stride_l;
+        h.bsz = p->bsz; h.n_q_heads = p->n_q_heads; h.n_kv_heads = p->n_kv_heads; h.group = p->n_q_heads / p->n_kv_heads;
+        h.q_len = p->q_len; h.window = p->window;
+        h.sqrt_d = (float)std::sqrt((double)p->head_dim);
+        const int rc = kvc::launch_h2o_scores(h, p->dtype, p->head_dim, st);
+        if (rc) return fail(rc, "no H2O kernel for dtype %d head_dim %d", p->dtype, p->head_dim);
+        return hip_ok("h2o scores launch");
+    }
     kvc::ScoreArgs a;
     a.q = q; a.k = k;
     a.logits = ws + l.logits;
@@ -122,6 +146,10 @@ int enqueue_scores(const kvc_params* p, const Layout& l, const void* q, const vo
     a.n_tiles = l.n_tiles; a.n_chunks = l.n_chunks;
     a.kernel_size = p->kernel_size; a.pooling = p->pooling;
     a.stage_mask = p->debug_stage_mask;
+    a.dbg = nullptr;
+#if defined(KVC_STAMPS)
+    a.dbg = reinterpret_cast<unsigned long long*>(scores);   // diagnostic build: stamps land in scores_out
+#endif
     a.sqrt_d = (float)std::sqrt((double)p->head_dim);   // math.sqrt(head_dim) -> fp32 (pyramidkv_utils.py:317)
     const int rc = kvc::launch_scores(a, p->dtype, p->head_dim, st);
     if (rc) return fail(rc, "no scoring kernel for dtype %d head_dim %d", p->dtype, p->head_dim);

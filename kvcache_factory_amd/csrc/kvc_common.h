@@ -21,11 +21,12 @@ template <> struct Dt<KVC_BF16> {
     typedef uint16_t raw;
     static constexpr int esize = 2;
     __device__ static __forceinline__ float ld(raw r) { return u2f((uint32_t)r << 16); }
-    __device__ static __forceinline__ raw st(float f) {   // RNE, NaN stays NaN
-        uint32_t u = f2u(f);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (raw)((u >> 16) | 0x0040u);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        return (raw)(u >> 16);
+    __device__ static __forceinline__ raw st(float f) {   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+        asm volatile("" : "+v"(f));                         // the fp32 value is rounded as such (no folding into the producer)
+        __bf16 h = (__bf16)f;
+        raw r;
+        __builtin_memcpy(&r, &h, 2);
+        return r;
     }
     __device__ static __forceinline__ float finfo_min() { return u2f(0xff7f0000u); }
 };

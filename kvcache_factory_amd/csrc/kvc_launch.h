@@ -19,6 +19,19 @@ struct ScoreArgs {
     int n_tiles, n_chunks, kernel_size, pooling;
     int stage_mask;        // 0 = all; bit0 logits, bit1 rowsum, bit2 pool (profiling aid)
     float sqrt_d;
+    unsigned long long* dbg;   // diagnostic stamps (KVC_STAMPS builds only), else null
+};
+
+struct H2OArgs {
+    const void* q; const void* k;
+    void* S;               // [bsz*Hq][L][L] dtype logits
+    float* rowmax;         // [bsz*Hq][L]
+    float* rinv;           // [bsz*Hq][L]
+    void* scores;          // [bsz*Hq][L-W] dtype
+    int64_t q_stride_b, q_stride_h, q_stride_l;
+    int64_t k_stride_b, k_stride_h, k_stride_l;
+    int bsz, n_q_heads, n_kv_heads, group, q_len, window;
+    float sqrt_d;
 };
 
 struct GatherArgs {
@@ -39,6 +52,7 @@ struct SelectArgs {
 struct GatherPair { GatherArgs t[2]; int count; };    // K and V compacted by one launch
 
 int launch_scores(const ScoreArgs& a, int dtype, int head_dim, hipStream_t st);
+int launch_h2o_scores(const H2OArgs& a, int dtype, int head_dim, hipStream_t st);
 int launch_select(const SelectArgs& a, int dtype, int tie_mode, hipStream_t st);
 size_t select_lds_bytes(int k);
 int launch_select_exact(const SelectArgs& a, int dtype, void* scratch, hipStream_t st);   // tie_mode torch_cpu

@@ -22,6 +22,21 @@ namespace kvc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Diagnostic build only (-DKVC_STAMPS): per-wave s_memtime stamps at phase boundaries of logits_kernel, written to
+// a buffer of their own (ScoreArgs::dbg) that nothing else reads.  Never enabled in the shipped library.
+#if defined(KVC_STAMPS)
+#define KVC_STAMP(slot)                                                                                       \
+    do {                                                                                                      \
+        unsigned long long t_;                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if (a.dbg && lane == 0) a.dbg[((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + (slot)] = t_; \
+    } while (0)
+#else
+#define KVC_STAMP(slot) do { } while (0)
+#endif
+
 // Pull the element with parity `kh` of bf16/fp16 pair s out of a 16-byte chunk (8 elements),
 // or of fp32 pair s out of a 16-byte chunk (4 elements).
 template <int DT> __device__ __forceinline__ float pick(const uint4& v, int s, int kh);
@@ -41,9 +56,31 @@ template <> __device__ __forceinline__ float pick<KVC_FP32>(const uint4& v, int 
 
 // ---------------------------------------------------------------------------------------------
 // logits_kernel
-// grid  = (ceil(L/128), bsz * n_kv_heads), block = 256 (4 waves x 32 keys)
-// LDS   = 128 * D * esize (K tile) + 4*32*4 (per-wave row maxima)
+// grid  = (blocks per KV head, bsz * n_kv_heads), block = 256 = 4 autonomous waves.
+// Each wave owns 32-key tiles  t = wave_id, wave_id + n_waves, ...  of its KV head: it stages the tile in its OWN
+// double-buffered LDS region (coalesced 16-B global loads -> registers -> XOR-swizzled ds_write), so there is no
+// workgroup barrier in the loop and the loads of tile t+1 fly while tile t is contracted:
+//   64 x v_mfma_f32_32x32x2_f32 per tile (the exact d-ascending fmaf chain), then the epilogue (3 roundings,
+//   mask), 8-byte packed stores of logits [h][key][w] and a running per-row maximum.
+// LDS   = 4 waves * 2 buffers * 32 keys * D * esize (+ 4*32 floats for the final cross-wave maximum)
 // ---------------------------------------------------------------------------------------------
+template <int D> struct ScaleDiv;            // x / sqrt(D) in fp32, bit-identical to the IEEE division
+template <> struct ScaleDiv<64> {            // sqrt(64) = 8: multiplying by 2^-3 IS the division (exact scaling)
+    __device__ static __forceinline__ float apply(float x, float) { return x * 0.125f; }
+};
+template <> struct ScaleDiv<128> {
+    // q0 = x*rc, r = fma(-q0, c, x), q = fma(r, rc, q0) equals RN(x / c) for c = sqrt(128) and EVERY finite fp32 x with
+    // |x| >= 2^-100 (checked exhaustively over all 2^32 inputs: tests/test_fastdiv.py); the rest takes the true division.
+    __device__ static __forceinline__ float apply(float x, float c) {
+        const float rc = u2f(0x3db504f3u);                         // RN(1 / sqrt(128))
+        const float ax = __builtin_fabsf(x);
+        if (__builtin_expect(!(ax >= u2f(0x0d800000u) && ax < __builtin_inff()), 0)) return x / c;
+        const float q0 = x * rc;
+        const float r = __builtin_fmaf(-q0, c, x);
+        return __builtin_fmaf(r, rc, q0);
+    }
+};
+
 template <int DT, int D, int WV>
 __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
     typedef typename Dt<DT>::raw raw;
@@ -52,48 +89,48 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
     constexpr int CH = ROWB / 16;            // 16-byte chunks per row
     constexpr int PAIRS = 8 / ES;            // mfma k-pairs per chunk: 4 (16-bit) or 2 (fp32)
     constexpr int SWZ = CH < 16 ? CH - 1 : 15;
+    constexpr int STG = CH / 2;              // staging registers (uint4) per lane per tile: 32*CH chunks / 64 lanes
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* wmax = reinterpret_cast<float*>(smem + 128 * ROWB);   // [4][32]
+    float* wmax = reinterpret_cast<float*>(smem + 4 * 2 * 32 * ROWB);   // [4][32]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
-    const int tile = blockIdx.x;
     const int b = blockIdx.y / a.n_kv_heads, g = blockIdx.y % a.n_kv_heads;
     const int L = a.q_len, W = WV > 0 ? WV : a.window, G = a.group;
-    const int key0 = tile * 128;
     const int rows = G * W;                   // query rows sharing this KV head
     const int n_mt = (rows + 31) / 32;
+    const int n_t = (L + 31) / 32;            // 32-key tiles of this head
+    const int wave_g = blockIdx.x * 4 + wave, n_waves = gridDim.x * 4;
+    char* const buf = smem + wave * (2 * 32 * ROWB);
+    const float sqrt_d = a.sqrt_d;
+    KVC_STAMP(0);
 
-    // ---- first M-tile's query row: issue the loads now, convert after the K tile is staged ----
-    uint4 qraw[CH];
-    {
-        const bool valid = j < rows;
-        const int hq = g * G + (valid ? j / W : 0), w = valid ? j % W : 0;
-        const char* qrow = reinterpret_cast<const char*>(a.q) +
-            ((int64_t)b * a.q_stride_b + (int64_t)hq * a.q_stride_h + (int64_t)(L - W + w) * a.q_stride_l) * ES;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) qraw[c] = valid ? *reinterpret_cast<const uint4*>(qrow + c * 16) : make_uint4(0, 0, 0, 0);
-    }
-
-    // ---- stage the K tile: 128 rows x CH chunks, coalesced, swizzled ----
     const char* kbase = reinterpret_cast<const char*>(a.k) +
                         ((int64_t)b * a.k_stride_b + (int64_t)g * a.k_stride_h) * ES;
-    for (int c = tid; c < 128 * CH; c += 256) {
-        const int r = c / CH, cc = c % CH;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (key0 + r < L)
-            v = *reinterpret_cast<const uint4*>(kbase + (int64_t)(key0 + r) * a.k_stride_l * ES + cc * 16);
-        *reinterpret_cast<uint4*>(smem + r * ROWB + ((cc ^ (r & SWZ)) * 16)) = v;
-    }
-    __syncthreads();
-
-    const int key = key0 + wave * 32 + j;
-    const float sqrt_d = a.sqrt_d;
-    const char* krow = smem + (wave * 32 + j) * ROWB;
+    // chunk ids of this lane inside a tile: c = it*64 + lane -> row c / CH, chunk c % CH
+    auto issue = [&](int tile, uint4 (&st)[STG]) {
+#pragma unroll
+        for (int it = 0; it < STG; ++it) {
+            const int c = it * 64 + lane, r = c / CH, cc = c % CH;
+            const int key = tile * 32 + r;
+            st[it] = key < L ? *reinterpret_cast<const uint4*>(kbase + (int64_t)key * a.k_stride_l * ES + cc * 16)
+                             : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto commit = [&](char* dst, const uint4 (&st)[STG]) {
+#pragma unroll
+        for (int it = 0; it < STG; ++it) {
+            const int c = it * 64 + lane, r = c / CH, cc = c % CH;
+            *reinterpret_cast<uint4*>(dst + r * ROWB + ((cc ^ (r & SWZ)) * 16)) = st[it];
+        }
+    };
 
     for (int mt = 0; mt < n_mt; ++mt) {
-        // ---- A operand: this lane's query row, its parity's elements, as fp32 ----
+        // ---- A operand: this lane's query row, its parity's elements, as fp32 (held for every tile) ----
         float areg[D / 2];
-        if (mt > 0) {
+        uint4 st[STG];
+        int tile = wave_g;
+        {
+            uint4 qraw[CH];
             const int i = mt * 32 + j;
             const bool valid = i < rows;
             const int hq = g * G + (valid ? i / W : 0), w = valid ? i % W : 0;
@@ -101,88 +138,114 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
                 ((int64_t)b * a.q_stride_b + (int64_t)hq * a.q_stride_h + (int64_t)(L - W + w) * a.q_stride_l) * ES;
 #pragma unroll
             for (int c = 0; c < CH; ++c) qraw[c] = valid ? *reinterpret_cast<const uint4*>(qrow + c * 16) : make_uint4(0, 0, 0, 0);
-        }
+            if (tile < n_t) issue(tile, st);
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
+            for (int c = 0; c < CH; ++c) {
 #pragma unroll
-            for (int s = 0; s < PAIRS; ++s) areg[c * PAIRS + s] = pick<DT>(qraw[c], s, kh);
-        }
-        // ---- 32 rows x 32 keys, chain over d = 0..D-1 in order ----
-        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const uint4 kv = *reinterpret_cast<const uint4*>(krow + ((c ^ (j & SWZ)) * 16));
-#pragma unroll
-            for (int s = 0; s < PAIRS; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c * PAIRS + s], pick<DT>(kv, s, kh), acc, 0, 0, 0);
-        }
-        // ---- epilogue: 3 roundings, mask, store [h][key][w], tile row maxima ----
-        float xs[16];
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            float x[4];
-            const int i0 = mt * 32 + 8 * rg + 4 * kh;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int w = (i0 + e) % W;
-                float v = rnd<DT>(acc[rg * 4 + e]);
-                v = rnd<DT>(v / sqrt_d);
-                if (key >= L - W && (key - (L - W)) > w) v = rnd<DT>(v + Dt<DT>::finfo_min());
-                x[e] = v;
-                xs[rg * 4 + e] = (key < L) ? v : -__builtin_inff();
+                for (int s = 0; s < PAIRS; ++s) areg[c * PAIRS + s] = pick<DT>(qraw[c], s, kh);
             }
-            if (i0 < rows && key < L) {
-                if ((W % 4) == 0) {
-                    const int hq = g * G + i0 / W, w0 = i0 % W;
-                    raw* dst = reinterpret_cast<raw*>(a.logits) + (((int64_t)b * a.n_q_heads + hq) * L + key) * W + w0;
-                    if constexpr (ES == 2) {
-                        uint2 pk;
-                        pk.x = (uint32_t)Dt<DT>::st(x[0]) | ((uint32_t)Dt<DT>::st(x[1]) << 16);
-                        pk.y = (uint32_t)Dt<DT>::st(x[2]) | ((uint32_t)Dt<DT>::st(x[3]) << 16);
-                        *reinterpret_cast<uint2*>(dst) = pk;
-                    } else {
-                        *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
-                    }
-                } else {
+        }
+        if (tile < n_t) commit(buf, st);
+        KVC_STAMP(1);
+        float runmax = -__builtin_inff();     // running maximum of this lane's row (see reduce-scatter below)
+        int cur = 0;
+        for (; tile < n_t; tile += n_waves) {
+            const int next = tile + n_waves;
+            if (next < n_t) issue(next, st);                  // in flight during the MFMAs below
+            __builtin_amdgcn_wave_barrier();
+            const char* krow = buf + cur * (32 * ROWB) + j * ROWB;
+            const int key = tile * 32 + j;
+            KVC_STAMP(2);
+            // ---- 32 rows x 32 keys, chain over d = 0..D-1 in order ----
+            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = i0 + e;
-                        if (i < rows) {
-                            const int hq = g * G + i / W, w = i % W;
-                            reinterpret_cast<raw*>(a.logits)[(((int64_t)b * a.n_q_heads + hq) * L + key) * W + w] = Dt<DT>::st(x[e]);
+            for (int c = 0; c < CH; ++c) {
+                const uint4 kv = *reinterpret_cast<const uint4*>(krow + ((c ^ (j & SWZ)) * 16));
+#pragma unroll
+                for (int s = 0; s < PAIRS; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c * PAIRS + s], pick<DT>(kv, s, kh), acc, 0, 0, 0);
+            }
+            asm volatile("" :: "v"(acc[0]), "v"(acc[15]));
+            KVC_STAMP(3);
+            // ---- epilogue: 3 roundings, mask, store [h][key][w] ----
+            const bool tail = tile * 32 + 32 > L - W;          // wave-uniform: tile touches the masked W x W block
+            float xs[16];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float x[4];
+                const int i0 = mt * 32 + 8 * rg + 4 * kh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = rnd<DT>(acc[rg * 4 + e]);
+                    v = rnd<DT>(ScaleDiv<D>::apply(v, sqrt_d));
+                    if (tail) {
+                        const int w = (i0 + e) % W;
+                        if (key >= L - W && (key - (L - W)) > w) v = rnd<DT>(v + Dt<DT>::finfo_min());
+                    }
+                    x[e] = v;
+                    xs[rg * 4 + e] = (key < L) ? v : -__builtin_inff();
+                }
+                if (i0 < rows && key < L) {
+                    if ((W % 4) == 0) {
+                        const int hq = g * G + i0 / W, w0 = i0 % W;
+                        raw* dst = reinterpret_cast<raw*>(a.logits) + (((int64_t)b * a.n_q_heads + hq) * L + key) * W + w0;
+                        if constexpr (ES == 2) {
+                            uint2 pk;
+                            pk.x = (uint32_t)Dt<DT>::st(x[0]) | ((uint32_t)Dt<DT>::st(x[1]) << 16);
+                            pk.y = (uint32_t)Dt<DT>::st(x[2]) | ((uint32_t)Dt<DT>::st(x[3]) << 16);
+                            *reinterpret_cast<uint2*>(dst) = pk;
+                        } else {
+                            *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int i = i0 + e;
+                            if (i < rows) {
+                                const int hq = g * G + i / W, w = i % W;
+                                reinterpret_cast<raw*>(a.logits)[(((int64_t)b * a.n_q_heads + hq) * L + key) * W + w] = Dt<DT>::st(x[e]);
+                            }
                         }
                     }
                 }
             }
+            KVC_STAMP(4);
+            // per-row maximum over this tile's 32 keys: reduce-scatter over the 5 key bits (16 cross-lane moves):
+            // after the step on lane bit t each lane keeps only the registers whose index bit matches its own.
+            {
+                const bool b4 = (j & 16) != 0, b3 = (j & 8) != 0, b2 = (j & 4) != 0, b1 = (j & 2) != 0;
+                float y[8], z[4], u[2];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float o = __shfl_xor(b4 ? xs[r] : xs[r + 8], 16);
+                    const float keep = b4 ? xs[r + 8] : xs[r];
+                    y[r] = o > keep ? o : keep;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float o = __shfl_xor(b3 ? y[r] : y[r + 4], 8);
+                    const float keep = b3 ? y[r + 4] : y[r];
+                    z[r] = o > keep ? o : keep;
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const float o = __shfl_xor(b2 ? z[r] : z[r + 2], 4);
+                    const float keep = b2 ? z[r + 2] : z[r];
+                    u[r] = o > keep ? o : keep;
+                }
+                float m = __shfl_xor(b1 ? u[0] : u[1], 2);
+                { const float keep = b1 ? u[1] : u[0]; m = m > keep ? m : keep; }
+                { const float o = __shfl_xor(m, 1); m = o > m ? o : m; }
+                runmax = m > runmax ? m : runmax;
+            }
+            KVC_STAMP(5);
+            if (next < n_t) commit(buf + (cur ^ 1) * (32 * ROWB), st);
+            cur ^= 1;
         }
-        // per-row maximum over this wave's 32 keys: reduce-scatter over the 5 key bits (16 cross-lane moves):
-        // after the step on lane bit t, each lane keeps only the registers whose index bit matches its own.
+        // ---- block-level maximum per row -> pmax[hq][blockIdx.x][w] ----
         {
-            const bool b4 = (j & 16) != 0, b3 = (j & 8) != 0, b2 = (j & 4) != 0, b1 = (j & 2) != 0;
-            float y[8], z[4], u[2];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const float o = __shfl_xor(b4 ? xs[r] : xs[r + 8], 16);
-                const float keep = b4 ? xs[r + 8] : xs[r];
-                y[r] = o > keep ? o : keep;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float o = __shfl_xor(b3 ? y[r] : y[r + 4], 8);
-                const float keep = b3 ? y[r + 4] : y[r];
-                z[r] = o > keep ? o : keep;
-            }
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const float o = __shfl_xor(b2 ? z[r] : z[r + 2], 4);
-                const float keep = b2 ? z[r + 2] : z[r];
-                u[r] = o > keep ? o : keep;
-            }
-            float m = __shfl_xor(b1 ? u[0] : u[1], 2);
-            { const float keep = b1 ? u[1] : u[0]; m = m > keep ? m : keep; }
-            { const float o = __shfl_xor(m, 1); m = o > m ? o : m; }
-            const int R = (b1 ? 1 : 0) + (b2 ? 2 : 0) + (b3 ? 4 : 0) + (b4 ? 8 : 0);     // accumulator register index
-            if ((j & 1) == 0) wmax[wave * 32 + (R & 3) + 8 * (R >> 2) + 4 * kh] = m;
+            const int R = ((j >> 1) & 1) + ((j >> 2) & 1) * 2 + ((j >> 3) & 1) * 4 + ((j >> 4) & 1) * 8;   // accumulator register
+            if ((j & 1) == 0) wmax[wave * 32 + (R & 3) + 8 * (R >> 2) + 4 * kh] = runmax;
         }
         __syncthreads();
         if (tid < 32) {
@@ -192,7 +255,7 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
 #pragma unroll
                 for (int wv = 1; wv < 4; ++wv) { const float o = wmax[wv * 32 + tid]; m = o > m ? o : m; }
                 const int hq = g * G + i / W, w = i % W;
-                a.pmax[(((int64_t)b * a.n_q_heads + hq) * a.n_tiles + tile) * W + w] = m;
+                a.pmax[(((int64_t)b * a.n_q_heads + hq) * a.n_tiles + blockIdx.x) * W + w] = m;
             }
         }
         __syncthreads();
@@ -371,7 +434,10 @@ static void launch_softmax_pool_t(const ScoreArgs& a, hipStream_t st) {
 template <int DT, int D, int WV>
 static void launch_all_t(const ScoreArgs& a, hipStream_t st) {
     constexpr int ES = Dt<DT>::esize;
-    const size_t lds = (size_t)128 * D * ES + 4 * 32 * sizeof(float);
+    const size_t lds = (size_t)4 * 2 * 32 * D * ES + 4 * 32 * sizeof(float);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&logits_kernel<DT, D, WV>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 g1((unsigned)a.n_tiles, (unsigned)(a.bsz * a.n_kv_heads));
     if ((a.stage_mask ? a.stage_mask : 7) & 1) hipLaunchKernelGGL((logits_kernel<DT, D, WV>), g1, dim3(256), lds, st, a);
     launch_softmax_pool_t<DT, WV>(a, st);

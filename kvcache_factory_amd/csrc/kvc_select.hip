@@ -24,7 +24,7 @@ static constexpr int SEL_MAX_EPT = 64;          // n <= 65536 candidates per hea
 size_t select_lds_bytes(int k) {
     int p = 1;
     while (p < k) p <<= 1;
-    return (size_t)p * 8 + 64 * 4;
+    return (size_t)p * 8 + (2 * SEL_WAVES + 256) * 4;
 }
 
 // Sum of one small per-thread count over the block; result broadcast to every thread.
@@ -116,15 +116,24 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a)
     // ---- 3. order ----
     int64_t* out = a.idx + (int64_t)head * k;
     if (k <= 256) {
-        // rank sort: composites are unique, rank = number of smaller composites
-        unsigned long long mine = 0;
-        uint32_t rank = 0;
-        if (tid < k) {
-            mine = list[tid];
-            for (int u = 0; u < k; ++u) rank += list[u] < mine ? 1u : 0u;
+        // rank sort spread over the whole workgroup: composites are unique, rank = number of smaller composites.
+        // thread t: element e = t % E (E = pow2 >= k), comparison slice t / E; slice partials are summed in LDS.
+        const int E = a.pow2 < 32 ? 32 : a.pow2;            // 32..256
+        const int slices = SEL_THREADS / E;                 // 4..32
+        const int e = tid % E, sl = tid / E;
+        const int per = (k + slices - 1) / slices;
+        uint32_t* rk = buf + 2 * SEL_WAVES;                 // [256] partial-rank accumulators (LDS, after the count buffers)
+        if (tid < E) rk[tid] = 0;
+        __syncthreads();
+        unsigned long long mine = e < k ? list[e] : 0ull;
+        if (e < k) {
+            uint32_t part = 0;
+            const int u0 = sl * per, u1 = u0 + per < k ? u0 + per : k;
+            for (int u = u0; u < u1; ++u) part += list[u] < mine ? 1u : 0u;
+            if (part) atomicAdd(&rk[e], part);
         }
         __syncthreads();
-        if (tid < k) list[rank] = mine;
+        if (tid < k) list[rk[tid]] = mine;                  // tid < k <= E: this thread's `mine` is element tid (slice 0)
         __syncthreads();
     } else {
         const int P = a.pow2;
@@ -145,27 +154,37 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a)
     }
     for (int t = tid; t < k; t += SEL_THREADS) out[t] = (int64_t)(list[t] & 0xffffffffull);
 
-    // ---- 4. fused gather of this head's rows (small k only) ----
+    // ---- 4. fused gather of this head's rows (small k only): all loads of a batch are issued before its stores ----
     if (a.fuse) {
         const int lanes_per_row = a.gk.row_bytes >> 4;
-        const int rows_per_pass = SEL_THREADS / lanes_per_row;
-        const int rr = tid / lanes_per_row, cc = tid % lanes_per_row;
         const int cap = k + a.gk.window;
+        const int per_tensor = cap * lanes_per_row;           // 16-byte pieces per tensor
+        const int total = 2 * per_tensor;
         const int b = head / a.gk.n_q_heads, h = head % a.gk.n_q_heads;
         const int64_t esz = a.gk.esize;
+        constexpr int BATCH = 4;
+        for (int base = 0; base < total; base += BATCH * SEL_THREADS) {
+            uint4 v[BATCH];
+            char* dst[BATCH];
 #pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            const GatherArgs& g = which == 0 ? a.gk : a.gv;
-            const char* sbase = reinterpret_cast<const char*>(g.src) + ((int64_t)b * g.stride_b + (int64_t)(h / g.group) * g.stride_h) * esz;
-            char* obase = reinterpret_cast<char*>(g.out) + (int64_t)head * cap * g.row_bytes;
-            for (int t0 = 0; t0 < cap; t0 += rows_per_pass) {
-                const int t = t0 + rr;
-                if (rr < rows_per_pass && t < cap) {
+            for (int u = 0; u < BATCH; ++u) {
+                const int piece = base + u * SEL_THREADS + tid;
+                dst[u] = nullptr;
+                if (piece < total) {
+                    const int which = piece >= per_tensor ? 1 : 0;
+                    const int pp = piece - which * per_tensor;
+                    const int t = pp / lanes_per_row, cc = pp % lanes_per_row;
+                    const GatherArgs& g = which == 0 ? a.gk : a.gv;
                     const int64_t srow = t < k ? (int64_t)(list[t] & 0xffffffffull) : (int64_t)(g.q_len - g.window) + (t - k);
-                    *reinterpret_cast<uint4*>(obase + (int64_t)t * g.row_bytes + cc * 16) =
-                        *reinterpret_cast<const uint4*>(sbase + srow * g.stride_l * esz + cc * 16);
+                    const char* src = reinterpret_cast<const char*>(g.src) +
+                        ((int64_t)b * g.stride_b + (int64_t)(h / g.group) * g.stride_h + srow * g.stride_l) * esz + cc * 16;
+                    v[u] = *reinterpret_cast<const uint4*>(src);
+                    dst[u] = reinterpret_cast<char*>(g.out) + ((int64_t)head * cap + t) * g.row_bytes + cc * 16;
                 }
             }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u)
+                if (dst[u]) *reinterpret_cast<uint4*>(dst[u]) = v[u];
         }
     }
 }

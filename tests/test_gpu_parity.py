@@ -138,6 +138,33 @@ def test_compress_exact_ties_equals_reference(kvc, gpu_device, name):
         assert G.sha(ko) == m["k_out_sha256"] and G.sha(vo) == m["v_out_sha256"]
 
 
+H2O = lambda m: m["method"] == "h2o" and not m["passthrough"]      # noqa: E731
+
+
+@pytest.mark.parametrize("name", G.names(H2O))
+def test_h2o_scores_bit_exact_vs_oracle_and_reference(kvc, oracle, gpu_device, name):
+    """A10: H2O scores (all L query rows, unmasked prefix rows, no pooling) == oracle bit for bit; end to end with
+    torch-CPU ties the indices and K'/V' equal the REFERENCE's golden vectors (bf16/fp16)."""
+    m, arr = G.MANIFEST[name], G.arrays(name)
+    small = m["L"] <= 1100
+    q, k, v = G.inputs(m, expanded=False) if small else [t.cpu() for t in G.inputs(m, device=gpu_device, expanded=False)]
+    qd, kd, vd = _to(gpu_device, q, k, v)
+    sc_g = kvc.scores(kvc.H2O, qd, kd, m["W"], m["kernel"], None)
+    sc_o = oracle.scores(q, k, m["W"], m["kernel"], "avgpool", full_rows=True, **G.product_modes(oracle, m))
+    assert torch.equal(G.bits(sc_g[0]), G.bits(sc_o))                       # tolerance: 0 ulp
+    ko, vo, idx = kvc.compress(kvc.H2O, qd, kd, vd, m["W"], m["n_keep"], m["kernel"], None, "torch_cpu", return_indices=True)
+    ref_idx = torch.from_numpy(arr["indices"])
+    if m["dtype"] == "fp32":
+        assert int((idx[0].cpu() == ref_idx).all(-1).sum()) >= m["Hq"] - 1
+    else:
+        assert torch.equal(idx[0].cpu(), ref_idx)
+        assert G.sha(ko) == m["k_out_sha256"] and G.sha(vo) == m["v_out_sha256"]
+    # canonical ties: same selected values, deterministic order
+    idx_c = kvc.compress(kvc.H2O, qd, kd, vd, m["W"], m["n_keep"], m["kernel"], None, "canonical", return_indices=True)[2]
+    idx_oc, _ = oracle.topk(sc_o, m["n_keep"], oracle.TIES_CANON)
+    assert torch.equal(idx_c[0].cpu(), idx_oc)
+
+
 @pytest.mark.parametrize("name", G.names(lambda m: m["method"] == "streamingllm" and not m["passthrough"]))
 def test_streamingllm_vs_reference(kvc, gpu_device, name):
     m = G.MANIFEST[name]

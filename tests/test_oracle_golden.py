@@ -16,7 +16,7 @@ import golden_util as G
 
 SCORED = lambda m: m["method"] != "streamingllm" and not m["passthrough"]          # noqa: E731
 SMALL = lambda m: SCORED(m) and m["L"] <= 1100                                      # noqa: E731
-CPU_BIG = ["C2_snapkv_8k_bf16", "C4_pyramidkv_8k_layer0", "C4_pyramidkv_8k_layer16"]
+CPU_BIG = ["C2_snapkv_8k_bf16", "C4_pyramidkv_8k_layer0", "C4_pyramidkv_8k_layer16"]   # (C3 H2O 8k: GPU suite)
 
 
 @functools.lru_cache(maxsize=2)
@@ -60,9 +60,8 @@ def test_scores_against_reference(oracle, name, mode):
     32 fp32 ulps (torch's softmax exp differs from exp_u20 in the last bits and nothing rounds it away)."""
     m, arr = G.MANIFEST[name], G.arrays(name)
     q, k, v = _inputs(m)
-    dot, sm = (oracle.DOT_CHAIN, oracle.SUM_KVC) if mode == "product" else (oracle.DOT_F64, oracle.SUM_TORCH16)
-    sc = oracle.scores(q, k, m["W"], m["kernel"], G.pool_name(m) or "avgpool", full_rows=m["method"] == "h2o",
-                       dot_mode=dot, sum_mode=sm)
+    modes = G.product_modes(oracle, m) if mode == "product" else dict(dot_mode=oracle.DOT_F64, sum_mode=oracle.SUM_TORCH16)
+    sc = oracle.scores(q, k, m["W"], m["kernel"], G.pool_name(m) or "avgpool", full_rows=m["method"] == "h2o", **modes)
     ref = G.from_bits(arr["scores"], G.DT[m["dtype"]])
     d = G.ulp_diff(sc, ref)
     if m["dtype"] == "fp32":
@@ -80,8 +79,8 @@ def test_end_to_end_indices_and_kv(oracle, name):
     m, arr = G.MANIFEST[name], G.arrays(name)
     q, k, v = _inputs(m)
     ko, vo, idx, sc = oracle.compress(q, k, v, m["W"], m["n_keep"], m["kernel"], G.pool_name(m) or "avgpool",
-                                      full_rows=m["method"] == "h2o", dot_mode=oracle.DOT_CHAIN,
-                                      sum_mode=oracle.SUM_KVC, tie_mode=oracle.TIES_TORCH)
+                                      full_rows=m["method"] == "h2o", tie_mode=oracle.TIES_TORCH,
+                                      **G.product_modes(oracle, m))
     ref_idx = torch.from_numpy(arr["indices"])
     heads_equal = int((idx == ref_idx).all(-1).sum())
     if m["dtype"] == "fp32":
