@@ -56,33 +56,87 @@ def layer_budgets(cfg):
     return [cfg["cap"] - cfg["W"]] * LAYERS
 
 
-def build_plans(cfg, dev, tie_mode, expanded, seed0=0):
+_STREAMS = {}
+
+
+def side_streams(dev, n):
+    """n HIP streams per device.  The 32 layer compressions of a prompt are independent, so the
+    drop-in calls are spread round-robin over a few streams exactly as a serving stack would overlap them."""
+    key = (dev.index, n)
+    if key not in _STREAMS:
+        _STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    return _STREAMS[key]
+
+
+def build_plans(cfg, dev, tie_mode, expanded, n_streams=1, seed0=0):
     plans = []
     ks = layer_budgets(cfg)
+    streams = side_streams(dev, n_streams)
     for l in range(LAYERS):
         q, k, v = synth.make_qkv(HQ, HKV, cfg["L"], D, cfg["dtype"], seed0 + l, expanded=expanded, device=dev)
         if expanded:
             k, v = k.contiguous(), v.contiguous()
-        plans.append(_kvc.CompressPlan(METHODS[cfg["method"]], q, k, v, cfg["W"], ks[l], cfg["kernel"], cfg["pooling"],
-                                       tie_mode, want_indices=True))
+        with torch.cuda.stream(streams[l % n_streams]):          # the plan's workspace belongs to its stream
+            plan = _kvc.CompressPlan(METHODS[cfg["method"]], q, k, v, cfg["W"], ks[l], cfg["kernel"], cfg["pooling"],
+                                     tie_mode, want_indices=True)
+        plan.stream_handle = ctypes.c_void_p(streams[l % n_streams].cuda_stream)
+        plans.append(plan)
+    torch.cuda.synchronize(dev)
     return plans, ks
 
 
-def run_step(plans, stream):
+def run_step(plans, stream=None):
     for p in plans:
-        p.run(stream)
+        p.run(stream if stream is not None else p.stream_handle)
 
 
-def time_steps(plans, steps, warmup, dev, dist):
-    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+def capture_step(plans, dev):
+    """One step (32 layer calls over their streams) as a HIP graph: fork from the capture stream, run, join.
+    Replaying it costs one host call per step instead of ~130 kernel launches."""
+    handles = {p.stream_handle.value for p in plans}
+    tstreams = [s for sl in _STREAMS.values() for s in sl if s.cuda_stream in handles and s.device == dev]
+    g = torch.cuda.CUDAGraph()
+    cap = torch.cuda.Stream(device=dev)
+    with torch.cuda.graph(g, stream=cap):
+        fork = torch.cuda.Event()
+        fork.record(cap)
+        for s in tstreams:
+            s.wait_event(fork)
+        run_step(plans)
+        for s in tstreams:
+            e = torch.cuda.Event()
+            e.record(s)
+            cap.wait_event(e)
+    return g
+
+
+def time_steps(plans, steps, warmup, dev, dist, graph=None):
+    if graph is not None:
+        for _ in range(warmup):
+            graph.replay()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            graph.replay()
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
     for _ in range(warmup):
-        run_step(plans, stream)
+        run_step(plans)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(steps):
-        run_step(plans, stream)
+        run_step(plans)
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
@@ -176,6 +230,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--tie-mode", default="canonical", choices=["canonical", "torch_cpu"])
+    ap.add_argument("--streams", type=int, default=16, help="HIP streams the 32 independent layer calls are spread over")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every kvc_compress call from the host instead of replaying a HIP graph of the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (expanded K/V, exact ties)")
     a = ap.parse_args()
@@ -193,8 +249,18 @@ def main():
     torch.cuda.set_device(dev)
     cfg = CONFIGS[a.config]
 
-    plans, ks = build_plans(cfg, dev, a.tie_mode, expanded=False)
-    dt = time_steps(plans, a.steps, a.warmup, dev, dist)
+    plans, ks = build_plans(cfg, dev, a.tie_mode, expanded=False, n_streams=a.streams)
+    run_step(plans)                      # first call outside any capture (one-time LDS attribute setup)
+    torch.cuda.synchronize(dev)
+    graph, launch_mode = None, "host-enqueued kvc_compress calls"
+    if not a.no_graph:
+        try:
+            graph = capture_step(plans, dev)
+            launch_mode = "HIP graph of the step (32 kvc_compress calls captured once, replayed per step)"
+        except Exception as e:  # pragma: no cover
+            launch_mode = f"host-enqueued (graph capture failed: {e})"
+            graph = None
+    dt = time_steps(plans, a.steps, a.warmup, dev, dist, graph)
     tokens_per_step = cfg["L"] * LAYERS
     value = world * a.steps * tokens_per_step / dt
 
@@ -204,7 +270,8 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": cfg["desc"], "name": a.config, "layers_per_step": LAYERS, "q_len": cfg["L"], "budget": cfg["cap"],
                    "kv_layout": "gqa_native [1,8,L,128] as the patched attention forward hands K/V over",
-                   "tie_mode": a.tie_mode, "per_layer_us": dt / a.steps / LAYERS * 1e6, "multi_gpu": "replicas, no collective"},
+                   "tie_mode": a.tie_mode, "streams": a.streams, "launch": launch_mode, "per_layer_us": dt / a.steps / LAYERS * 1e6,
+                   "multi_gpu": "replicas, no collective"},
     }
     if rank == 0:
         # ---- roofline of the dominant kernel (K scan), live HIP-event timing ----
@@ -221,14 +288,23 @@ def main():
             extra = {}
             other = "torch_cpu" if a.tie_mode == "canonical" else "canonical"
             try:
-                p2, _ = build_plans(cfg, dev, other, expanded=False)
+                p2, _ = build_plans(cfg, dev, other, expanded=False, n_streams=a.streams)
                 d2 = time_steps(p2, max(2, a.steps // 2), 1, dev, None)
                 extra[f"tokens_per_s_tie_mode_{other}"] = max(2, a.steps // 2) * tokens_per_step / d2
                 del p2
             except Exception as e:
                 extra[f"tie_mode_{other}_error"] = str(e)
             try:
-                p3, _ = build_plans(cfg, dev, a.tie_mode, expanded=True)
+                p1, _ = build_plans(cfg, dev, a.tie_mode, expanded=False, n_streams=1)
+                d1 = time_steps(p1, max(2, a.steps // 2), 1, dev, None)
+                extra["tokens_per_s_single_stream_host_enqueued"] = max(2, a.steps // 2) * tokens_per_step / d1
+                d1b = time_steps(plans, max(2, a.steps // 2), 1, dev, None)
+                extra["tokens_per_s_multi_stream_host_enqueued"] = max(2, a.steps // 2) * tokens_per_step / d1b
+                del p1
+            except Exception as e:
+                extra["single_stream_error"] = str(e)
+            try:
+                p3, _ = build_plans(cfg, dev, a.tie_mode, expanded=True, n_streams=a.streams)
                 d3 = time_steps(p3, max(2, a.steps // 2), 1, dev, None)
                 extra["tokens_per_s_expanded_kv_as_reference_passes"] = max(2, a.steps // 2) * tokens_per_step / d3
                 del p3

@@ -25,7 +25,7 @@ inline int esize_of(int dtype) { return dtype == KVC_FP32 ? 4 : 2; }
 inline bool scoring(int method) { return method == KVC_SNAPKV || method == KVC_PYRAMIDKV || method == KVC_H2O; }
 
 struct Layout {
-    size_t logits, pmax, psum, rowmax, rowsum, scores, idx, exact, total;   // H2O: logits = S [L][L], rowmax/rowsum = [L] per head
+    size_t logits, ebuf, pmax, psum, rowmax, rowsum, scores, idx, exact, total;   // H2O: logits = S [L][L], rowmax/rowsum = [L] per head
     int n_tiles, n_chunks;
 };
 
@@ -85,6 +85,7 @@ Layout carve(const kvc_params* p) {
     if (scoring(p->method)) {
         const size_t R = p->method == KVC_H2O ? L : W;     // query rows that score
         l.logits = off; off = align_up(off + heads * L * R * es, 256);
+        l.ebuf = off;   off = align_up(off + (p->method == KVC_H2O ? 0 : heads * L * W * 4), 256);
         l.pmax = off;   off = align_up(off + (p->method == KVC_H2O ? 0 : heads * (size_t)l.n_tiles * W * 4), 256);
         l.psum = off;   off = align_up(off + (p->method == KVC_H2O ? 0 : heads * (size_t)l.n_chunks * W * 4), 256);
         l.rowmax = off; off = align_up(off + heads * R * 4, 256);
@@ -133,6 +134,7 @@ int enqueue_scores(const kvc_params* p, const Layout& l, const void* q, const vo
     kvc::ScoreArgs a;
     a.q = q; a.k = k;
     a.logits = ws + l.logits;
+    a.ebuf = reinterpret_cast<float*>(ws + l.ebuf);
     a.pmax = reinterpret_cast<float*>(ws + l.pmax);
     a.psum = reinterpret_cast<float*>(ws + l.psum);
     a.rowmax = reinterpret_cast<float*>(ws + l.rowmax);

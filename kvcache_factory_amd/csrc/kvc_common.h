@@ -129,14 +129,46 @@ template <> struct Key<KVC_FP32> {
     __device__ static __forceinline__ uint32_t of(float f) { uint32_t u = f2u(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 };
 
+// Value held by lane (l ^ MASK), MASK in {1,2,4,8,16,32}: DPP quad_perm / row shifts and the gfx950 permlane swaps —
+// plain VALU moves, no LDS round trip (a ds_bpermute costs ~120 cycles of latency per step; checked on the GPU by
+// tools/dpp_probe.hip).
+template <int MASK> __device__ __forceinline__ float xor_lane(float v) {
+    const int x = __float_as_int(v);
+    int r;
+    if constexpr (MASK == 1) r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);          // quad_perm [1,0,3,2]
+    else if constexpr (MASK == 2) r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);     // quad_perm [2,3,0,1]
+    else if constexpr (MASK == 4) {                                                                  // row_shl:4 | row_shr:4
+        r = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);
+        r = __builtin_amdgcn_update_dpp(r, x, 0x114, 0xF, 0xA, false);
+    } else if constexpr (MASK == 8) {                                                                // row_shl:8 | row_shr:8
+        r = __builtin_amdgcn_update_dpp(x, x, 0x108, 0xF, 0x3, false);
+        r = __builtin_amdgcn_update_dpp(r, x, 0x118, 0xF, 0xC, false);
+    } else if constexpr (MASK == 16) {
+        auto p = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        r = (threadIdx.x & 16) ? p[0] : p[1];
+    } else {
+        auto p = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        r = (threadIdx.x & 32) ? p[0] : p[1];
+    }
+    return __int_as_float(r);
+}
+
 __device__ __forceinline__ float wave_xor_sum(float v) {   // butterfly 1,2,4,8,16,32 (oracle: sum_kvc)
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) v = v + __shfl_xor(v, s);
+    v = v + xor_lane<1>(v);
+    v = v + xor_lane<2>(v);
+    v = v + xor_lane<4>(v);
+    v = v + xor_lane<8>(v);
+    v = v + xor_lane<16>(v);
+    v = v + xor_lane<32>(v);
     return v;
 }
 __device__ __forceinline__ float half_xor_max(float v) {   // max over the 32 lanes sharing lane>>5
-#pragma unroll
-    for (int s = 1; s < 32; s <<= 1) { const float o = __shfl_xor(v, s); v = o > v ? o : v; }
+    float o;
+    o = xor_lane<1>(v); v = o > v ? o : v;
+    o = xor_lane<2>(v); v = o > v ? o : v;
+    o = xor_lane<4>(v); v = o > v ? o : v;
+    o = xor_lane<8>(v); v = o > v ? o : v;
+    o = xor_lane<16>(v); v = o > v ? o : v;
     return v;
 }
 

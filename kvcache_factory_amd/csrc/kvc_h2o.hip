@@ -149,10 +149,10 @@ __global__ __launch_bounds__(256) void h2o_rowsum_kernel(const H2OArgs a) {
         for (; d < full; d += 16) acc = acc + exp_u20(Dt<DT>::ld(row[d + l]) - m);
         if (l < L - d) acc = acc + exp_u20(Dt<DT>::ld(row[d + l]) - m);
         // xor butterfly 8,4,2,1 inside each 16-lane group (fp32 add is commutative: both partners get the same bits)
-        acc = acc + __shfl_xor(acc, 8);
-        acc = acc + __shfl_xor(acc, 4);
-        acc = acc + __shfl_xor(acc, 2);
-        acc = acc + __shfl_xor(acc, 1);
+        acc = acc + xor_lane<8>(acc);
+        acc = acc + xor_lane<4>(acc);
+        acc = acc + xor_lane<2>(acc);
+        acc = acc + xor_lane<1>(acc);
         s = acc;
     }
     if (valid && l == 0) a.rinv[(int64_t)hb * L + r] = 1.0f / s;
@@ -181,8 +181,11 @@ template <int DT, int D>
 static int launch_h2o_t(const H2OArgs& a, hipStream_t st) {
     constexpr int ES = Dt<DT>::esize;
     const size_t lds = (size_t)4 * 2 * 32 * D * ES;
-    if (lds > 64 * 1024)
+    static size_t lds_ok = 0;
+    if (lds > 64 * 1024 && lds > lds_ok) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&h2o_logits_kernel<DT, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_ok = lds;
+    }
     const int L = a.q_len, n = L - a.window, heads = a.bsz * a.n_q_heads;
     const int row_tiles = (L + 31) / 32;
     hipLaunchKernelGGL((h2o_logits_kernel<DT, D>), dim3((unsigned)((row_tiles + 3) / 4), (unsigned)heads), dim3(256), lds, st, a);

@@ -8,6 +8,7 @@ namespace kvc {
 struct ScoreArgs {
     const void* q; const void* k;
     void* logits;          // [bsz*Hq][L][W] dtype
+    float* ebuf;           // [bsz*Hq][L][W] fp32: exp(logit - rowmax), written by rowsum_kernel, read by pool_kernel
     float* pmax;           // [bsz*Hq][n_tiles][W]
     float* psum;           // [bsz*Hq][n_chunks][W]
     float* rowmax;         // [bsz*Hq][W]

@@ -217,25 +217,25 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
                 float y[8], z[4], u[2];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    const float o = __shfl_xor(b4 ? xs[r] : xs[r + 8], 16);
+                    const float o = xor_lane<16>(b4 ? xs[r] : xs[r + 8]);
                     const float keep = b4 ? xs[r + 8] : xs[r];
                     y[r] = o > keep ? o : keep;
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float o = __shfl_xor(b3 ? y[r] : y[r + 4], 8);
+                    const float o = xor_lane<8>(b3 ? y[r] : y[r + 4]);
                     const float keep = b3 ? y[r + 4] : y[r];
                     z[r] = o > keep ? o : keep;
                 }
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    const float o = __shfl_xor(b2 ? z[r] : z[r + 2], 4);
+                    const float o = xor_lane<4>(b2 ? z[r] : z[r + 2]);
                     const float keep = b2 ? z[r + 2] : z[r];
                     u[r] = o > keep ? o : keep;
                 }
-                float m = __shfl_xor(b1 ? u[0] : u[1], 2);
+                float m = xor_lane<2>(b1 ? u[0] : u[1]);
                 { const float keep = b1 ? u[1] : u[0]; m = m > keep ? m : keep; }
-                { const float o = __shfl_xor(m, 1); m = o > m ? o : m; }
+                { const float o = xor_lane<1>(m); m = o > m ? o : m; }
                 runmax = m > runmax ? m : runmax;
             }
             KVC_STAMP(5);
@@ -329,11 +329,21 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const ScoreArgs a) {
     const int key = chunk * 256 + tid;
     float x[WV > 0 ? WV : 64];
     if (key < L) load_logits<DT, WV>(reinterpret_cast<const raw*>(a.logits) + ((int64_t)hb * L + key) * W, W, x);
+    float* const erow = a.ebuf + ((int64_t)hb * L + (key < L ? key : 0)) * W;       // e = exp(x - max), kept for pool_kernel
 #pragma unroll
     for (int w = 0; w < (WV > 0 ? WV : W); ++w) {
         float e = (key < L) ? exp_u20(x[w] - m[w]) : 0.0f;
+        x[w] = e;
         e = wave_xor_sum(e);
         if (lane == 0) wsum[wave * 64 + w] = e;
+    }
+    if (key < L) {
+        if constexpr (WV > 0) {
+#pragma unroll
+            for (int c = 0; c < WV / 4; ++c) reinterpret_cast<float4*>(erow)[c] = make_float4(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);
+        } else {
+            for (int w = 0; w < W; ++w) erow[w] = x[w];
+        }
     }
     __syncthreads();
     if (tid < W) {
@@ -383,14 +393,20 @@ __global__ __launch_bounds__(256) void pool_kernel(const ScoreArgs a) {
         float sv = 0.0f;
         if (key >= 0 && key < n) {
             float x[WV > 0 ? WV : 64];
-            load_logits<DT, WV>(reinterpret_cast<const raw*>(a.logits) + ((int64_t)hb * L + key) * W, W, x);
+            const float* erow = a.ebuf + ((int64_t)hb * L + key) * W;
+            if constexpr (WV > 0) {
+#pragma unroll
+                for (int c = 0; c < WV / 4; ++c) {
+                    const float4 v = reinterpret_cast<const float4*>(erow)[c];
+                    x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
+                }
+            } else {
+                for (int w = 0; w < W; ++w) x[w] = erow[w];
+            }
             CascadeSum cs;
             cs.init(W);
 #pragma unroll
-            for (int w = 0; w < (WV > 0 ? WV : W); ++w) {
-                const float e = exp_u20(x[w] - m[w]);
-                cs.add(rnd<DT>(e * rinv[w]));
-            }
+            for (int w = 0; w < (WV > 0 ? WV : W); ++w) cs.add(rnd<DT>(x[w] * rinv[w]));
             sv = rnd<DT>(cs.result());
         }
         s_tile[t] = sv;
@@ -435,9 +451,12 @@ template <int DT, int D, int WV>
 static void launch_all_t(const ScoreArgs& a, hipStream_t st) {
     constexpr int ES = Dt<DT>::esize;
     const size_t lds = (size_t)4 * 2 * 32 * D * ES + 4 * 32 * sizeof(float);
-    if (lds > 64 * 1024)
+    static size_t lds_ok = 0;        // raise the dynamic-LDS limit once per instantiation, never inside the launch path again
+    if (lds > 64 * 1024 && lds > lds_ok) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&logits_kernel<DT, D, WV>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_ok = lds;
+    }
     dim3 g1((unsigned)a.n_tiles, (unsigned)(a.bsz * a.n_kv_heads));
     if ((a.stage_mask ? a.stage_mask : 7) & 1) hipLaunchKernelGGL((logits_kernel<DT, D, WV>), g1, dim3(256), lds, st, a);
     launch_softmax_pool_t<DT, WV>(a, st);

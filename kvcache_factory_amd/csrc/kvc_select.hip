@@ -2,11 +2,12 @@
 // `attn_cache.topk(k, dim=-1).indices`) on gfx950, optionally followed in the same workgroup by A8 (the
 // gather of that head's K/V rows) when k is small.
 //
-// select_kernel: one 1024-thread workgroup per head, the head's scores held in registers as
+// select_kernel: one 256-thread workgroup per head, the head's scores held in registers as
 // order-preserving integer keys (thread t owns candidates [t*EPT, (t+1)*EPT)).
 //   1. threshold: bit-by-bit search of the k-th largest key T (one block-wide count per key bit:
 //      16 rounds for bf16/fp16, 32 for fp32) — no atomics, no histogram contention on the few hundred
-//      distinct values a head really has;
+//      distinct values a head really has.  Measured issue-bound (stamps, round 1): 4 waves x 32 keys per lane
+//      spend a third of the instructions of 16 waves x 8 keys;
 //   2. membership: every key > T, plus the r = k - count(key > T) candidates equal to T chosen by tie_mode:
 //        KVC_TIES_CANONICAL  lowest index first (ordered block scan);
 //   3. order: value descending, index ascending (rank sort in LDS for k <= 256, bitonic sort otherwise);
@@ -17,9 +18,23 @@
 
 namespace kvc {
 
-static constexpr int SEL_THREADS = 1024;
+// Diagnostic build only (-DKVC_STAMPS): phase stamps of wave 0, written over this head's index output.
+#if defined(KVC_STAMPS)
+#define KVC_SSTAMP(slot)                                                                     \
+    do {                                                                                     \
+        unsigned long long t_;                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");         \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        if (tid == 0) stamps_[slot] = t_;                                                    \
+    } while (0)
+#else
+#define KVC_SSTAMP(slot) do { } while (0)
+#endif
+
+static constexpr int SEL_THREADS = 256;            // 4 waves = one per SIMD: the search is issue-bound, extra waves only repeat scalar work
 static constexpr int SEL_WAVES = SEL_THREADS / 64;
-static constexpr int SEL_MAX_EPT = 64;          // n <= 65536 candidates per head
+static constexpr int SEL_MAX_EPT = 256;         // n <= 65536 candidates per head
 
 size_t select_lds_bytes(int k) {
     int p = 1;
@@ -27,7 +42,30 @@ size_t select_lds_bytes(int k) {
     return (size_t)p * 8 + (2 * SEL_WAVES + 256) * 4;
 }
 
-// Sum of one small per-thread count over the block; result broadcast to every thread.
+// Wave-wide sum / exclusive prefix of a SMALL per-lane count (< 2^NB) without any LDS round trip: one ballot per
+// value bit, popcount (s_bcnt1) for the total and mbcnt for the lanes below.  (The ds_bpermute butterflies these
+// replace cost ~120 cycles per step and dominated the kernel: stamps, round 1.)
+template <int NB>
+__device__ __forceinline__ uint32_t wave_sum_small(uint32_t v) {
+    uint32_t s = 0;
+#pragma unroll
+    for (int bit = 0; bit < NB; ++bit) s += (uint32_t)__popcll(__ballot((v >> bit) & 1u)) << bit;
+    return s;
+}
+template <int NB>
+__device__ __forceinline__ uint32_t wave_excl_scan_small(uint32_t v, uint32_t* wave_total) {
+    uint32_t pre = 0, tot = 0;
+#pragma unroll
+    for (int bit = 0; bit < NB; ++bit) {
+        const unsigned long long m = __ballot((v >> bit) & 1u);
+        pre += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << bit;
+        tot += (uint32_t)__popcll(m) << bit;
+    }
+    *wave_total = tot;
+    return pre;
+}
+
+// Sum of one wave-uniform count over the block; result broadcast to every thread.
 // `slot` alternates between two LDS arrays so that one barrier per call is enough.
 __device__ __forceinline__ uint32_t block_sum(uint32_t wave_total, uint32_t* buf /*[2][SEL_WAVES]*/, int slot) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -39,22 +77,49 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t wave_total, uint32_t* buf
     return s;
 }
 
-// Exclusive prefix (in thread order) of a per-thread count, plus the block total.
+// Exclusive prefix (in thread order) of a small per-thread count, plus the block total.
+template <int NB>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* buf, int slot, uint32_t* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(inc, off);
-        if (lane >= off) inc += o;
-    }
-    if (lane == 63) buf[slot * SEL_WAVES + wave] = inc;
+    uint32_t wtot;
+    const uint32_t pre = wave_excl_scan_small<NB>(v, &wtot);
+    if (lane == 0) buf[slot * SEL_WAVES + wave] = wtot;
     __syncthreads();
     uint32_t base = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < SEL_WAVES; ++w) { const uint32_t c = buf[slot * SEL_WAVES + w]; if (w < wave) base += c; tot += c; }
     *total = tot;
-    return base + inc - v;
+    return base + pre;
+}
+
+// Copy one head's k selected rows + W tail rows of one tensor in 16-byte pieces; the 8 loads of a batch are all
+// issued (unconditionally, clamped) before its stores so the batch stays in registers and the latencies overlap.
+__device__ __forceinline__ void gather_head_rows(const unsigned long long* list, int k, int64_t tail0, int per_tensor,
+                                                 int lanes_per_row, int64_t esz, const char* sbase, char* obase,
+                                                 int64_t stride_l) {
+    const int tid = threadIdx.x;
+    for (int base = 0; base < per_tensor; base += 8 * SEL_THREADS) {
+        uint4 v0, v1, v2, v3, v4, v5, v6, v7;
+#define KVC_GLOAD(V, U)                                                                                     \
+        {                                                                                                   \
+            const int piece = base + (U) * SEL_THREADS + tid;                                               \
+            const int pc = piece < per_tensor ? piece : per_tensor - 1;                                     \
+            const int t = pc / lanes_per_row, cc = pc - t * lanes_per_row;                                  \
+            const int64_t srow = t < k ? (int64_t)(list[t] & 0xffffffffull) : tail0 + t;                    \
+            V = *reinterpret_cast<const uint4*>(sbase + srow * stride_l * esz + cc * 16);                   \
+        }
+        KVC_GLOAD(v0, 0) KVC_GLOAD(v1, 1) KVC_GLOAD(v2, 2) KVC_GLOAD(v3, 3)
+        KVC_GLOAD(v4, 4) KVC_GLOAD(v5, 5) KVC_GLOAD(v6, 6) KVC_GLOAD(v7, 7)
+#undef KVC_GLOAD
+#define KVC_GSTORE(V, U)                                                                                    \
+        {                                                                                                   \
+            const int piece = base + (U) * SEL_THREADS + tid;                                               \
+            if (piece < per_tensor) *reinterpret_cast<uint4*>(obase + (int64_t)piece * 16) = V;             \
+        }
+        KVC_GSTORE(v0, 0) KVC_GSTORE(v1, 1) KVC_GSTORE(v2, 2) KVC_GSTORE(v3, 3)
+        KVC_GSTORE(v4, 4) KVC_GSTORE(v5, 5) KVC_GSTORE(v6, 6) KVC_GSTORE(v7, 7)
+#undef KVC_GSTORE
+    }
 }
 
 template <int DT, int EPT>
@@ -70,23 +135,49 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a)
     const int head = blockIdx.x;
     const raw* s = reinterpret_cast<const raw*>(a.scores) + (int64_t)head * n;
 
+#if defined(KVC_STAMPS)
+    unsigned long long stamps_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    KVC_SSTAMP(0);
     // ---- candidates into registers ----
+    constexpr int NB = EPT <= 8 ? 4 : EPT <= 32 ? 6 : EPT <= 64 ? 7 : EPT <= 128 ? 8 : 9;   // bits of a per-thread count
+    constexpr int ES = Dt<DT>::esize, PER16 = 16 / ES;
     uint32_t key[EPT];
     const int i0 = tid * EPT;
+    if ((reinterpret_cast<uintptr_t>(s) & 15) == 0 && i0 + EPT <= n) {       // whole 16-byte pieces, coalesced
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) key[e] = (i0 + e < n) ? Key<DT>::of(s[i0 + e]) : 0u;
+        for (int c = 0; c < EPT / PER16; ++c) {
+            const uint4 v = reinterpret_cast<const uint4*>(s + i0)[c];
+            const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                if constexpr (ES == 2) {
+                    key[c * 8 + 2 * d] = Key<DT>::of((raw)(wd[d] & 0xffffu));
+                    key[c * 8 + 2 * d + 1] = Key<DT>::of((raw)(wd[d] >> 16));
+                } else {
+                    key[c * 4 + d] = Key<DT>::of(u2f(wd[d]));
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) key[e] = (i0 + e < n) ? Key<DT>::of(s[i0 + e]) : 0u;
+    }
 
+    asm volatile("" :: "v"(key[0]), "v"(key[EPT - 1]));
+    KVC_SSTAMP(1);
     // ---- 1. threshold: largest T with count(key >= T) >= k ----
     uint32_t T = 0;
     int slot = 0;
     for (int bit = KB - 1; bit >= 0; --bit) {
         const uint32_t cand = T | (1u << bit);
-        uint32_t c = 0;
+        uint32_t ct = 0;                                     // padded keys are 0 and cand >= 1: they never count
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) c += (uint32_t)__popcll(__ballot(key[e] >= cand && (i0 + e) < n));
-        if (block_sum(c, buf, slot) >= (uint32_t)k) T = cand;
+        for (int e = 0; e < EPT; ++e) ct += key[e] >= cand ? 1u : 0u;
+        if (block_sum(wave_sum_small<NB>(ct), buf, slot) >= (uint32_t)k) T = cand;
         slot ^= 1;
     }
+    KVC_SSTAMP(2);
     // ---- 2. membership ----
     uint32_t cg = 0, ce = 0;
 #pragma unroll
@@ -96,11 +187,11 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a)
         ce += (valid && key[e] == T) ? 1u : 0u;
     }
     uint32_t tot_gt, tot_eq, tot_take;
-    (void)block_excl_scan(cg, buf, slot, &tot_gt); slot ^= 1;
+    (void)block_excl_scan<NB>(cg, buf, slot, &tot_gt); slot ^= 1;
     const uint32_t r = (uint32_t)k - tot_gt;                       // ties needed (>= 1)
-    const uint32_t eq_before = block_excl_scan(ce, buf, slot, &tot_eq); slot ^= 1;
+    const uint32_t eq_before = block_excl_scan<NB>(ce, buf, slot, &tot_eq); slot ^= 1;
     const uint32_t eq_take = eq_before >= r ? 0u : (r - eq_before < ce ? r - eq_before : ce);
-    uint32_t pos = block_excl_scan(cg + eq_take, buf, slot, &tot_take); slot ^= 1;
+    uint32_t pos = block_excl_scan<NB>(cg + eq_take, buf, slot, &tot_take); slot ^= 1;
     {
         uint32_t eq_seen = 0;
 #pragma unroll
@@ -112,6 +203,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a)
         }
     }
     __syncthreads();
+    KVC_SSTAMP(3);
 
     // ---- 3. order ----
     int64_t* out = a.idx + (int64_t)head * k;
@@ -129,6 +221,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a)
         if (e < k) {
             uint32_t part = 0;
             const int u0 = sl * per, u1 = u0 + per < k ? u0 + per : k;
+#pragma unroll 8
             for (int u = u0; u < u1; ++u) part += list[u] < mine ? 1u : 0u;
             if (part) atomicAdd(&rk[e], part);
         }
@@ -152,50 +245,41 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a)
             }
         }
     }
+    KVC_SSTAMP(4);
     for (int t = tid; t < k; t += SEL_THREADS) out[t] = (int64_t)(list[t] & 0xffffffffull);
 
-    // ---- 4. fused gather of this head's rows (small k only): all loads of a batch are issued before its stores ----
+    // ---- 4. fused gather of this head's rows (small k only): a batch's loads are all issued before its stores ----
     if (a.fuse) {
         const int lanes_per_row = a.gk.row_bytes >> 4;
         const int cap = k + a.gk.window;
         const int per_tensor = cap * lanes_per_row;           // 16-byte pieces per tensor
-        const int total = 2 * per_tensor;
         const int b = head / a.gk.n_q_heads, h = head % a.gk.n_q_heads;
-        const int64_t esz = a.gk.esize;
-        constexpr int BATCH = 4;
-        for (int base = 0; base < total; base += BATCH * SEL_THREADS) {
-            uint4 v[BATCH];
-            char* dst[BATCH];
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int piece = base + u * SEL_THREADS + tid;
-                dst[u] = nullptr;
-                if (piece < total) {
-                    const int which = piece >= per_tensor ? 1 : 0;
-                    const int pp = piece - which * per_tensor;
-                    const int t = pp / lanes_per_row, cc = pp % lanes_per_row;
-                    const GatherArgs& g = which == 0 ? a.gk : a.gv;
-                    const int64_t srow = t < k ? (int64_t)(list[t] & 0xffffffffull) : (int64_t)(g.q_len - g.window) + (t - k);
-                    const char* src = reinterpret_cast<const char*>(g.src) +
-                        ((int64_t)b * g.stride_b + (int64_t)(h / g.group) * g.stride_h + srow * g.stride_l) * esz + cc * 16;
-                    v[u] = *reinterpret_cast<const uint4*>(src);
-                    dst[u] = reinterpret_cast<char*>(g.out) + ((int64_t)head * cap + t) * g.row_bytes + cc * 16;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u)
-                if (dst[u]) *reinterpret_cast<uint4*>(dst[u]) = v[u];
-        }
+        const int64_t esz = a.gk.esize, row_bytes = a.gk.row_bytes;
+        const int64_t tail0 = (int64_t)(a.gk.q_len - a.gk.window) - k;
+        const int hk = h / a.gk.group;
+        gather_head_rows(list, k, tail0, per_tensor, lanes_per_row, esz,
+                         reinterpret_cast<const char*>(a.gk.src) + ((int64_t)b * a.gk.stride_b + (int64_t)hk * a.gk.stride_h) * esz,
+                         reinterpret_cast<char*>(a.gk.out) + (int64_t)head * cap * row_bytes, a.gk.stride_l);
+        gather_head_rows(list, k, tail0, per_tensor, lanes_per_row, esz,
+                         reinterpret_cast<const char*>(a.gv.src) + ((int64_t)b * a.gv.stride_b + (int64_t)hk * a.gv.stride_h) * esz,
+                         reinterpret_cast<char*>(a.gv.out) + (int64_t)head * cap * row_bytes, a.gv.stride_l);
     }
+#if defined(KVC_STAMPS)
+    __syncthreads();
+    KVC_SSTAMP(5);
+    if (tid == 0) for (int i = 0; i < 6; ++i) out[i] = (int64_t)stamps_[i];
+#endif
 }
 
 template <int DT, int EPT>
 static int launch_t(const SelectArgs& a, hipStream_t st) {
     const size_t lds = select_lds_bytes(a.k);
-    if (lds > 64 * 1024) {
+    static size_t lds_ok = 0;
+    if (lds > 64 * 1024 && lds > lds_ok) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&select_kernel<DT, EPT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return KVC_ERR_HIP;
+        lds_ok = lds;
     }
     hipLaunchKernelGGL((select_kernel<DT, EPT>), dim3((unsigned)a.heads), dim3(SEL_THREADS), lds, st, a);
     return 0;
@@ -205,8 +289,9 @@ template <int DT>
 static int launch_dt(const SelectArgs& a, hipStream_t st) {
     const int ept = (a.n + SEL_THREADS - 1) / SEL_THREADS;
     if (ept <= 8) return launch_t<DT, 8>(a, st);
-    if (ept <= 16) return launch_t<DT, 16>(a, st);
     if (ept <= 32) return launch_t<DT, 32>(a, st);
+    if (ept <= 64) return launch_t<DT, 64>(a, st);
+    if (ept <= 128) return launch_t<DT, 128>(a, st);
     if (ept <= SEL_MAX_EPT) return launch_t<DT, SEL_MAX_EPT>(a, st);
     return KVC_ERR_UNSUPPORTED;
 }

@@ -83,10 +83,12 @@ static int launch_exact_t(const SelectArgs& a, void* scratch, hipStream_t st) {
     const size_t elems = partial ? (size_t)a.k : (in_lds ? (size_t)a.n : 0);
     const size_t lds = 1152 + elems * 8;
     if (!in_lds && !scratch) return KVC_ERR_WORKSPACE;
-    if (lds > 64 * 1024) {
+    static size_t lds_ok = 0;
+    if (lds > 64 * 1024 && lds > lds_ok) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&select_exact_kernel<DT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return KVC_ERR_HIP;
+        lds_ok = lds;
     }
     hipLaunchKernelGGL((select_exact_kernel<DT>), dim3((unsigned)a.heads), dim3(64), lds, st, a,
                        reinterpret_cast<u64*>(scratch), in_lds);

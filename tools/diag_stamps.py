@@ -29,3 +29,18 @@ print("  wave total mean", float((t[:, 5] - t[:, 0]).mean()), " kernel span", fl
 # start-time spread of blocks
 s0 = t[:, 0] - t[:, 0].min()
 print("  wave start offsets: p50", float(s0.median()), "p90", float(s0.quantile(0.9)), "max", float(s0.max()))
+
+# ---- select_kernel phases (wave 0 of each head) ----
+p2 = _kvc.make_params(_kvc.SNAPKV, q, k, v, W, 120, 7, "maxpool", "canonical")
+ko = torch.empty(1, 32, 128, 128, dtype=torch.bfloat16, device=dev); vo = torch.empty_like(ko)
+idx = torch.zeros(1, 32, 120, dtype=torch.int64, device=dev)
+nb = _kvc.lib().kvc_workspace_bytes(ctypes.byref(p2)); ws2 = _kvc.workspace(dev, nb)
+for it in range(3):
+    rc = _kvc.lib().kvc_compress(ctypes.byref(p2), _kvc._ptr(q), _kvc._ptr(k), _kvc._ptr(v), _kvc._ptr(ko), _kvc._ptr(vo), _kvc._ptr(idx), None, _kvc._ptr(ws2), nb, st)
+    assert rc == 0, _kvc.lib().kvc_last_error()
+    torch.cuda.synchronize()
+ts = idx[0, :, :6].cpu().double()
+dd = ts[:, 1:] - ts[:, :-1]
+for i, nm in enumerate(["load keys", "threshold bit search (16 rounds)", "membership scans + list", "order (rank sort)", "idx store + fused gather"]):
+    print(f"  select: {nm:36s} mean {dd[:, i].mean():9.1f} max {dd[:, i].max():9.1f}")
+print("  select total", float((ts[:, 5] - ts[:, 0]).mean()))
