@@ -110,6 +110,26 @@ def capture_step(plans, dev):
     return g
 
 
+def reduce_max_time(dt, dist, device):
+    """Every rank times its own replica; the job time is the slowest rank's (MAX all-reduce; RCCL on GPUs, gloo in the
+    CPU test).  No data-path collective exists on this path."""
+    if dist is None:
+        return dt
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def job_value(world, steps, tokens_per_step, dt):
+    """Whole-job throughput of `world` independent replicas (weak scaling): all ranks' tokens over the max time."""
+    return world * steps * tokens_per_step / dt
+
+
+def rank_seed(rank):
+    """Replicas compress different prompts: layer seeds are offset per rank."""
+    return 1000 * rank
+
+
 def time_steps(plans, steps, warmup, dev, dist, graph=None):
     if graph is not None:
         for _ in range(warmup):
@@ -123,12 +143,7 @@ def time_steps(plans, steps, warmup, dev, dist, graph=None):
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+        return reduce_max_time(time.perf_counter() - t0, dist, dev)
     for _ in range(warmup):
         run_step(plans)
     if dist is not None:
@@ -140,12 +155,7 @@ def time_steps(plans, steps, warmup, dev, dist, graph=None):
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return dt
+    return reduce_max_time(time.perf_counter() - t0, dist, dev)
 
 
 def time_scan_kernel(plans, dev, reps=20):
@@ -179,7 +189,11 @@ def cpu_baseline(cfg, budget_s=12.0):
     """The CPU oracle (a port of the reference's algorithm, oracle/kvc_oracle.cpp) timed on this host's cores on a
     bounded sample of the same workload: whole layer calls of the bench config, repeated for ~budget_s seconds."""
     from oracle import kvc_oracle as O      # cpu_baseline leg only (the checker, timed as the baseline)
-    threads = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))          # the GPU box gives one GPU's share of the host: 16 cores
     L = cfg["L"]
     q, k, v = synth.make_qkv(HQ, HKV, L, D, cfg["dtype"], 0)
     n_keep = layer_budgets(cfg)[0]
@@ -249,7 +263,7 @@ def main():
     torch.cuda.set_device(dev)
     cfg = CONFIGS[a.config]
 
-    plans, ks = build_plans(cfg, dev, a.tie_mode, expanded=False, n_streams=a.streams)
+    plans, ks = build_plans(cfg, dev, a.tie_mode, expanded=False, n_streams=a.streams, seed0=rank_seed(rank))
     run_step(plans)                      # first call outside any capture (one-time LDS attribute setup)
     torch.cuda.synchronize(dev)
     graph, launch_mode = None, "host-enqueued kvc_compress calls"
@@ -262,7 +276,7 @@ def main():
             graph = None
     dt = time_steps(plans, a.steps, a.warmup, dev, dist, graph)
     tokens_per_step = cfg["L"] * LAYERS
-    value = world * a.steps * tokens_per_step / dt
+    value = job_value(world, a.steps, tokens_per_step, dt)
 
     out = {
         "metric": "KV tokens compressed/sec", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
@@ -284,6 +298,18 @@ def main():
                            "path_achieved_GBs": path_b / (dt / a.steps / LAYERS) / 1e9,
                            "path_frac": path_b / (dt / a.steps / LAYERS) / 1e9 / HBM_PEAK_GBS,
                            "path_algorithmic_bytes_per_layer": path_b}
+        try:      # HBM bytes of the K-scan kernel from the committed PMC pass (profiles/, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE;
+            #   gfx950 correction: FETCH_SIZE counts half of a wide coalesced read).  KB per dispatch -> bytes per launch.
+            import csv
+            def _pmc(name):
+                with open(os.path.join(ROOT, "profiles", f"r01_pmc_{name}.csv")) as fh:
+                    return [float(r["mean_per_dispatch"]) for r in csv.DictReader(fh)
+                            if r["kernel"].startswith("kvc::logits_kernel") and r["counter"] == name][0]
+            if a.config == "c2":
+                out["roofline"]["traffic"] = (2.0 * _pmc("FETCH_SIZE") + _pmc("WRITE_SIZE")) * 1024.0
+                out["roofline"]["traffic_source"] = "profiles/r01_pmc_{FETCH,WRITE}_SIZE.csv (separate --pmc passes of the same kernel)"
+        except Exception:
+            pass
         if not a.no_extras and world == 1:
             extra = {}
             other = "torch_cpu" if a.tie_mode == "canonical" else "canonical"
