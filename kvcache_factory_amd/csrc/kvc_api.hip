@@ -148,6 +148,7 @@ int enqueue_scores(const kvc_params* p, const Layout& l, const void* q, const vo
     a.n_tiles = l.n_tiles; a.n_chunks = l.n_chunks;
     a.kernel_size = p->kernel_size; a.pooling = p->pooling;
     a.stage_mask = p->debug_stage_mask;
+    a.nbuf = ((p->q_len + 31) / 32 + l.n_tiles * 4 - 1) / (l.n_tiles * 4) > 1 ? 2 : 1;
     a.dbg = nullptr;
 #if defined(KVC_STAMPS)
     a.dbg = reinterpret_cast<unsigned long long*>(scores);   // diagnostic build: stamps land in scores_out

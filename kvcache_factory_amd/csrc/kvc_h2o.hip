@@ -23,7 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int DT> __device__ __forceinline__ float pick2(const uint4& v, int s, int kh);
 template <> __device__ __forceinline__ float pick2<KVC_BF16>(const uint4& v, int s, int kh) {
     const uint32_t w = s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w;
-    return u2f(kh ? (w & 0xffff0000u) : (w << 16));
+    return u2f(__builtin_amdgcn_perm(w, w, kh ? 0x07060c0cu : 0x05040c0cu));
 }
 template <> __device__ __forceinline__ float pick2<KVC_FP16>(const uint4& v, int s, int kh) {
     const uint32_t w = s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w;

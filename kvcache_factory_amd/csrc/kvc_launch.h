@@ -18,6 +18,7 @@ struct ScoreArgs {
     int64_t k_stride_b, k_stride_h, k_stride_l;
     int bsz, n_q_heads, n_kv_heads, group, q_len, window;
     int n_tiles, n_chunks, kernel_size, pooling;
+    int nbuf;              // K-tile buffers per wave in logits_kernel: 1 if every wave owns a single tile, else 2
     int stage_mask;        // 0 = all; bit0 logits, bit1 rowsum, bit2 pool (profiling aid)
     float sqrt_d;
     unsigned long long* dbg;   // diagnostic stamps (KVC_STAMPS builds only), else null

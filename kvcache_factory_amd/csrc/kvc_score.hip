@@ -37,20 +37,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define KVC_STAMP(slot) do { } while (0)
 #endif
 
-// Pull the element with parity `kh` of bf16/fp16 pair s out of a 16-byte chunk (8 elements),
-// or of fp32 pair s out of a 16-byte chunk (4 elements).
-template <int DT> __device__ __forceinline__ float pick(const uint4& v, int s, int kh);
-template <> __device__ __forceinline__ float pick<KVC_BF16>(const uint4& v, int s, int kh) {
+// Pull the element with parity kh (= lane >> 5) of bf16/fp16 pair s out of a 16-byte chunk (8 elements), or of fp32
+// pair s out of a 16-byte chunk (4 elements), widened to fp32.  `sel` is the per-lane constant lane_sel<DT>(kh):
+// one v_perm_b32 per bf16 element (selector moves the chosen half to the top and zero-fills), shift+cvt for fp16.
+template <int DT> __device__ __forceinline__ uint32_t lane_sel(int kh);
+template <> __device__ __forceinline__ uint32_t lane_sel<KVC_BF16>(int kh) { return kh ? 0x07060c0cu : 0x05040c0cu; }
+template <> __device__ __forceinline__ uint32_t lane_sel<KVC_FP16>(int kh) { return kh ? 16u : 0u; }
+template <> __device__ __forceinline__ uint32_t lane_sel<KVC_FP32>(int kh) { return (uint32_t)kh; }
+template <int DT> __device__ __forceinline__ float pick(const uint4& v, int s, uint32_t sel);
+template <> __device__ __forceinline__ float pick<KVC_BF16>(const uint4& v, int s, uint32_t sel) {
     const uint32_t w = s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w;
-    return u2f(kh ? (w & 0xffff0000u) : (w << 16));
+    return u2f(__builtin_amdgcn_perm(w, w, sel));
 }
-template <> __device__ __forceinline__ float pick<KVC_FP16>(const uint4& v, int s, int kh) {
+template <> __device__ __forceinline__ float pick<KVC_FP16>(const uint4& v, int s, uint32_t sel) {
     const uint32_t w = s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w;
-    return Dt<KVC_FP16>::ld((uint16_t)(kh ? (w >> 16) : (w & 0xffffu)));
+    return Dt<KVC_FP16>::ld((uint16_t)(w >> sel));
 }
-template <> __device__ __forceinline__ float pick<KVC_FP32>(const uint4& v, int s, int kh) {
+template <> __device__ __forceinline__ float pick<KVC_FP32>(const uint4& v, int s, uint32_t sel) {
     // chunk holds d = 4c..4c+3; pair s in {0,1} -> elements 2s, 2s+1
-    const uint32_t w = s == 0 ? (kh ? v.y : v.x) : (kh ? v.w : v.z);
+    const uint32_t w = s == 0 ? (sel ? v.y : v.x) : (sel ? v.w : v.z);
     return u2f(w);
 }
 
@@ -90,17 +95,25 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
     constexpr int PAIRS = 8 / ES;            // mfma k-pairs per chunk: 4 (16-bit) or 2 (fp32)
     constexpr int SWZ = CH < 16 ? CH - 1 : 15;
     constexpr int STG = CH / 2;              // staging registers (uint4) per lane per tile: 32*CH chunks / 64 lanes
+    constexpr int IMGROW = (D / 2) * 4;      // bytes of one lane's fp32 A-fragment (D/2 values)
+    constexpr int ICH = IMGROW / 16;         // its 16-byte chunks
+    constexpr int ISWZ = ICH < 16 ? ICH - 1 : 15;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* wmax = reinterpret_cast<float*>(smem + 4 * 2 * 32 * ROWB);   // [4][32]
+    // LDS: [Q image: 64 lanes x D/2 fp32, chunk-swizzled] [4 waves x nbuf x 32-key tile] [4 x 32 floats]
+    char* const img = smem;
+    const int nbuf = a.nbuf;
+    char* const tiles = smem + 64 * IMGROW;
+    float* wmax = reinterpret_cast<float*>(tiles + 4 * nbuf * 32 * ROWB);   // [4][32]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+    const uint32_t psel = lane_sel<DT>(kh);
     const int b = blockIdx.y / a.n_kv_heads, g = blockIdx.y % a.n_kv_heads;
     const int L = a.q_len, W = WV > 0 ? WV : a.window, G = a.group;
     const int rows = G * W;                   // query rows sharing this KV head
     const int n_mt = (rows + 31) / 32;
     const int n_t = (L + 31) / 32;            // 32-key tiles of this head
     const int wave_g = blockIdx.x * 4 + wave, n_waves = gridDim.x * 4;
-    char* const buf = smem + wave * (2 * 32 * ROWB);
+    char* const buf = tiles + wave * (nbuf * 32 * ROWB);
     const float sqrt_d = a.sqrt_d;
     KVC_STAMP(0);
 
@@ -125,26 +138,36 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
     };
 
     for (int mt = 0; mt < n_mt; ++mt) {
-        // ---- A operand: this lane's query row, its parity's elements, as fp32 (held for every tile) ----
-        float areg[D / 2];
+        // ---- A operand: the workgroup converts the 32 query rows of this M-tile ONCE into an fp32 image in LDS, laid
+        // out as the MFMA A-fragment of every lane (lane = row + 32*parity, value s = Q[row][2s + parity]); the four
+        // waves then read their fragment chunk by chunk inside the MFMA loop instead of holding D/2 registers each.
         uint4 st[STG];
         int tile = wave_g;
+        if (tile < n_t) issue(tile, st);
+        if (mt > 0) __syncthreads();                       // previous image no longer read
         {
-            uint4 qraw[CH];
-            const int i = mt * 32 + j;
-            const bool valid = i < rows;
-            const int hq = g * G + (valid ? i / W : 0), w = valid ? i % W : 0;
-            const char* qrow = reinterpret_cast<const char*>(a.q) +
-                ((int64_t)b * a.q_stride_b + (int64_t)hq * a.q_stride_h + (int64_t)(L - W + w) * a.q_stride_l) * ES;
+            constexpr int PER_ROW = ROWB / 16;             // 16-byte pieces of one query row
+            for (int pc = tid; pc < 32 * PER_ROW; pc += 256) {
+                const int r = pc / PER_ROW, cc = pc % PER_ROW;
+                const int i = mt * 32 + r;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (i < rows) {
+                    const int hq = g * G + i / W, w = i % W;
+                    const char* qrow = reinterpret_cast<const char*>(a.q) +
+                        ((int64_t)b * a.q_stride_b + (int64_t)hq * a.q_stride_h + (int64_t)(L - W + w) * a.q_stride_l) * ES;
+                    v = *reinterpret_cast<const uint4*>(qrow + cc * 16);
+                }
+                // this piece holds pairs s = cc*PAIRS .. cc*PAIRS+PAIRS-1; element s of lane-row l sits in chunk s/4
 #pragma unroll
-            for (int c = 0; c < CH; ++c) qraw[c] = valid ? *reinterpret_cast<const uint4*>(qrow + c * 16) : make_uint4(0, 0, 0, 0);
-            if (tile < n_t) issue(tile, st);
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
-#pragma unroll
-                for (int s = 0; s < PAIRS; ++s) areg[c * PAIRS + s] = pick<DT>(qraw[c], s, kh);
+                for (int sp = 0; sp < PAIRS; ++sp) {
+                    const int sidx = cc * PAIRS + sp;
+                    const int chunk = sidx >> 2, e = sidx & 3;
+                    *reinterpret_cast<float*>(img + r * IMGROW + ((chunk ^ (r & ISWZ)) * 16) + e * 4) = pick<DT>(v, sp, lane_sel<DT>(0));
+                    *reinterpret_cast<float*>(img + (32 + r) * IMGROW + ((chunk ^ ((32 + r) & ISWZ)) * 16) + e * 4) = pick<DT>(v, sp, lane_sel<DT>(1));
+                }
             }
         }
+        __syncthreads();
         if (tile < n_t) commit(buf, st);
         KVC_STAMP(1);
         float runmax = -__builtin_inff();     // running maximum of this lane's row (see reduce-scatter below)
@@ -154,16 +177,23 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
             if (next < n_t) issue(next, st);                  // in flight during the MFMAs below
             __builtin_amdgcn_wave_barrier();
             const char* krow = buf + cur * (32 * ROWB) + j * ROWB;
+            const char* arow = img + lane * IMGROW;
             const int key = tile * 32 + j;
             KVC_STAMP(2);
             // ---- 32 rows x 32 keys, chain over d = 0..D-1 in order ----
             f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                const uint4 kv = *reinterpret_cast<const uint4*>(krow + ((c ^ (j & SWZ)) * 16));
+            for (int ic = 0; ic < ICH; ++ic) {                 // one A chunk = 4 fragment values = 4 MFMAs
+                const float4 av = *reinterpret_cast<const float4*>(arow + ((ic ^ (lane & ISWZ)) * 16));
+                const float af[4] = {av.x, av.y, av.z, av.w};
 #pragma unroll
-                for (int s = 0; s < PAIRS; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c * PAIRS + s], pick<DT>(kv, s, kh), acc, 0, 0, 0);
+                for (int kc = 0; kc < 4 / PAIRS; ++kc) {       // K chunks feeding these 4 values: 1 (16-bit) or 2 (fp32)
+                    const int c = ic * (4 / PAIRS) + kc;
+                    const uint4 kv = *reinterpret_cast<const uint4*>(krow + ((c ^ (j & SWZ)) * 16));
+#pragma unroll
+                    for (int s = 0; s < PAIRS; ++s)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc * PAIRS + s], pick<DT>(kv, s, psel), acc, 0, 0, 0);
+                }
             }
             asm volatile("" :: "v"(acc[0]), "v"(acc[15]));
             KVC_STAMP(3);
@@ -239,8 +269,7 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
                 runmax = m > runmax ? m : runmax;
             }
             KVC_STAMP(5);
-            if (next < n_t) commit(buf + (cur ^ 1) * (32 * ROWB), st);
-            cur ^= 1;
+            if (next < n_t) { commit(buf + ((cur + 1) % nbuf) * (32 * ROWB), st); cur = (cur + 1) % nbuf; }
         }
         // ---- block-level maximum per row -> pmax[hq][blockIdx.x][w] ----
         {
@@ -450,7 +479,7 @@ static void launch_softmax_pool_t(const ScoreArgs& a, hipStream_t st) {
 template <int DT, int D, int WV>
 static void launch_all_t(const ScoreArgs& a, hipStream_t st) {
     constexpr int ES = Dt<DT>::esize;
-    const size_t lds = (size_t)4 * 2 * 32 * D * ES + 4 * 32 * sizeof(float);
+    const size_t lds = (size_t)64 * (D / 2) * 4 + (size_t)4 * a.nbuf * 32 * D * ES + 4 * 32 * sizeof(float);
     static size_t lds_ok = 0;        // raise the dynamic-LDS limit once per instantiation, never inside the launch path again
     if (lds > 64 * 1024 && lds > lds_ok) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&logits_kernel<DT, D, WV>),

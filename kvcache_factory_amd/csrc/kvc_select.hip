@@ -32,14 +32,13 @@ namespace kvc {
 #define KVC_SSTAMP(slot) do { } while (0)
 #endif
 
-static constexpr int SEL_THREADS = 256;            // 4 waves = one per SIMD: the search is issue-bound, extra waves only repeat scalar work
-static constexpr int SEL_WAVES = SEL_THREADS / 64;
+static constexpr int SEL_MAX_WAVES = 16;           // workgroup size THR is a template parameter: 256, 512 or 1024 threads
 static constexpr int SEL_MAX_EPT = 256;         // n <= 65536 candidates per head
 
 size_t select_lds_bytes(int k) {
     int p = 1;
     while (p < k) p <<= 1;
-    return (size_t)p * 8 + (2 * SEL_WAVES + 256) * 4;
+    return (size_t)p * 8 + (2 * SEL_MAX_WAVES + 256) * 4;
 }
 
 // Wave-wide sum / exclusive prefix of a SMALL per-lane count (< 2^NB) without any LDS round trip: one ballot per
@@ -67,33 +66,35 @@ __device__ __forceinline__ uint32_t wave_excl_scan_small(uint32_t v, uint32_t* w
 
 // Sum of one wave-uniform count over the block; result broadcast to every thread.
 // `slot` alternates between two LDS arrays so that one barrier per call is enough.
-__device__ __forceinline__ uint32_t block_sum(uint32_t wave_total, uint32_t* buf /*[2][SEL_WAVES]*/, int slot) {
+template <int SEL_WAVES>
+__device__ __forceinline__ uint32_t block_sum(uint32_t wave_total, uint32_t* buf /*[2][SEL_MAX_WAVES]*/, int slot) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) buf[slot * SEL_WAVES + wave] = wave_total;
+    if (lane == 0) buf[slot * SEL_MAX_WAVES + wave] = wave_total;
     __syncthreads();
     uint32_t s = 0;
 #pragma unroll
-    for (int w = 0; w < SEL_WAVES; ++w) s += buf[slot * SEL_WAVES + w];
+    for (int w = 0; w < SEL_WAVES; ++w) s += buf[slot * SEL_MAX_WAVES + w];
     return s;
 }
 
 // Exclusive prefix (in thread order) of a small per-thread count, plus the block total.
-template <int NB>
+template <int NB, int SEL_WAVES>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* buf, int slot, uint32_t* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t wtot;
     const uint32_t pre = wave_excl_scan_small<NB>(v, &wtot);
-    if (lane == 0) buf[slot * SEL_WAVES + wave] = wtot;
+    if (lane == 0) buf[slot * SEL_MAX_WAVES + wave] = wtot;
     __syncthreads();
     uint32_t base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < SEL_WAVES; ++w) { const uint32_t c = buf[slot * SEL_WAVES + w]; if (w < wave) base += c; tot += c; }
+    for (int w = 0; w < SEL_WAVES; ++w) { const uint32_t c = buf[slot * SEL_MAX_WAVES + w]; if (w < wave) base += c; tot += c; }
     *total = tot;
     return base + pre;
 }
 
 // Copy one head's k selected rows + W tail rows of one tensor in 16-byte pieces; the 8 loads of a batch are all
 // issued (unconditionally, clamped) before its stores so the batch stays in registers and the latencies overlap.
+template <int SEL_THREADS>
 __device__ __forceinline__ void gather_head_rows(const unsigned long long* list, int k, int64_t tail0, int per_tensor,
                                                  int lanes_per_row, int64_t esz, const char* sbase, char* obase,
                                                  int64_t stride_l) {
@@ -122,8 +123,9 @@ __device__ __forceinline__ void gather_head_rows(const unsigned long long* list,
     }
 }
 
-template <int DT, int EPT>
+template <int DT, int EPT, int SEL_THREADS>
 __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a) {
+    constexpr int SEL_WAVES = SEL_THREADS / 64;
     typedef typename Dt<DT>::raw raw;
     constexpr int KB = Key<DT>::bits;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -171,10 +173,11 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a)
     int slot = 0;
     for (int bit = KB - 1; bit >= 0; --bit) {
         const uint32_t cand = T | (1u << bit);
-        uint32_t ct = 0;                                     // padded keys are 0 and cand >= 1: they never count
+        uint32_t ct = 0, ct2 = 0;                            // padded keys are 0 and cand >= 1: they never count
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) ct += key[e] >= cand ? 1u : 0u;
-        if (block_sum(wave_sum_small<NB>(ct), buf, slot) >= (uint32_t)k) T = cand;
+        for (int e = 0; e < EPT; e += 2) { ct += key[e] >= cand ? 1u : 0u; ct2 += key[e + 1] >= cand ? 1u : 0u; }
+        ct += ct2;
+        if (block_sum<SEL_WAVES>(wave_sum_small<NB>(ct), buf, slot) >= (uint32_t)k) T = cand;
         slot ^= 1;
     }
     KVC_SSTAMP(2);
@@ -187,11 +190,11 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a)
         ce += (valid && key[e] == T) ? 1u : 0u;
     }
     uint32_t tot_gt, tot_eq, tot_take;
-    (void)block_excl_scan<NB>(cg, buf, slot, &tot_gt); slot ^= 1;
+    (void)block_excl_scan<NB, SEL_WAVES>(cg, buf, slot, &tot_gt); slot ^= 1;
     const uint32_t r = (uint32_t)k - tot_gt;                       // ties needed (>= 1)
-    const uint32_t eq_before = block_excl_scan<NB>(ce, buf, slot, &tot_eq); slot ^= 1;
+    const uint32_t eq_before = block_excl_scan<NB, SEL_WAVES>(ce, buf, slot, &tot_eq); slot ^= 1;
     const uint32_t eq_take = eq_before >= r ? 0u : (r - eq_before < ce ? r - eq_before : ce);
-    uint32_t pos = block_excl_scan<NB>(cg + eq_take, buf, slot, &tot_take); slot ^= 1;
+    uint32_t pos = block_excl_scan<NB, SEL_WAVES>(cg + eq_take, buf, slot, &tot_take); slot ^= 1;
     {
         uint32_t eq_seen = 0;
 #pragma unroll
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a)
         const int slices = SEL_THREADS / E;                 // 4..32
         const int e = tid % E, sl = tid / E;
         const int per = (k + slices - 1) / slices;
-        uint32_t* rk = buf + 2 * SEL_WAVES;                 // [256] partial-rank accumulators (LDS, after the count buffers)
+        uint32_t* rk = buf + 2 * SEL_MAX_WAVES;                 // [256] partial-rank accumulators (LDS, after the count buffers)
         if (tid < E) rk[tid] = 0;
         __syncthreads();
         unsigned long long mine = e < k ? list[e] : 0ull;
@@ -257,10 +260,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a)
         const int64_t esz = a.gk.esize, row_bytes = a.gk.row_bytes;
         const int64_t tail0 = (int64_t)(a.gk.q_len - a.gk.window) - k;
         const int hk = h / a.gk.group;
-        gather_head_rows(list, k, tail0, per_tensor, lanes_per_row, esz,
+        gather_head_rows<SEL_THREADS>(list, k, tail0, per_tensor, lanes_per_row, esz,
                          reinterpret_cast<const char*>(a.gk.src) + ((int64_t)b * a.gk.stride_b + (int64_t)hk * a.gk.stride_h) * esz,
                          reinterpret_cast<char*>(a.gk.out) + (int64_t)head * cap * row_bytes, a.gk.stride_l);
-        gather_head_rows(list, k, tail0, per_tensor, lanes_per_row, esz,
+        gather_head_rows<SEL_THREADS>(list, k, tail0, per_tensor, lanes_per_row, esz,
                          reinterpret_cast<const char*>(a.gv.src) + ((int64_t)b * a.gv.stride_b + (int64_t)hk * a.gv.stride_h) * esz,
                          reinterpret_cast<char*>(a.gv.out) + (int64_t)head * cap * row_bytes, a.gv.stride_l);
     }
@@ -271,28 +274,30 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a)
 #endif
 }
 
-template <int DT, int EPT>
+template <int DT, int EPT, int THR>
 static int launch_t(const SelectArgs& a, hipStream_t st) {
     const size_t lds = select_lds_bytes(a.k);
     static size_t lds_ok = 0;
     if (lds > 64 * 1024 && lds > lds_ok) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&select_kernel<DT, EPT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&select_kernel<DT, EPT, THR>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return KVC_ERR_HIP;
         lds_ok = lds;
     }
-    hipLaunchKernelGGL((select_kernel<DT, EPT>), dim3((unsigned)a.heads), dim3(SEL_THREADS), lds, st, a);
+    hipLaunchKernelGGL((select_kernel<DT, EPT, THR>), dim3((unsigned)a.heads), dim3(THR), lds, st, a);
     return 0;
 }
 
+// (threads, keys per thread): two waves per SIMD hide the dependent-issue latency of the per-key compares (one wave per
+// SIMD measured ~1.3 k cycles per search round); more waves only repeat the per-round scalar work.
 template <int DT>
 static int launch_dt(const SelectArgs& a, hipStream_t st) {
-    const int ept = (a.n + SEL_THREADS - 1) / SEL_THREADS;
-    if (ept <= 8) return launch_t<DT, 8>(a, st);
-    if (ept <= 32) return launch_t<DT, 32>(a, st);
-    if (ept <= 64) return launch_t<DT, 64>(a, st);
-    if (ept <= 128) return launch_t<DT, 128>(a, st);
-    if (ept <= SEL_MAX_EPT) return launch_t<DT, SEL_MAX_EPT>(a, st);
+    const int n = a.n;
+    if (n <= 2048) return launch_t<DT, 8, 256>(a, st);
+    if (n <= 8192) return launch_t<DT, 16, 512>(a, st);
+    if (n <= 16384) return launch_t<DT, 32, 512>(a, st);
+    if (n <= 32768) return launch_t<DT, 64, 512>(a, st);
+    if (n <= 65536) return launch_t<DT, 64, 1024>(a, st);
     return KVC_ERR_UNSUPPORTED;
 }
 
