@@ -103,6 +103,19 @@ int kvc_compress(const kvc_params* p, const void* q, const void* k, const void* 
                  void* k_out, void* v_out, int64_t* idx_out, void* scores_out,
                  void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* Batched form: n_items independent update_kv calls of IDENTICAL shape/dtype/strides (described by *p; p->k is
+ * ignored) and per-item budgets k_per_item[i] — e.g. the 32 layers of one prompt (the reference runs them as 32
+ * sequential calls, llama_model.py:285; they do not depend on each other).  Every kernel is launched once for up to
+ * 32 items, so the small per-call kernels stop being launch-latency bound.  The arrays are HOST arrays of DEVICE
+ * pointers (they are copied into the kernel arguments; nothing is staged on the device).  idx_out / scores_out may be
+ * NULL, as may their entries.  Results are identical to n_items kvc_compress calls.
+ * Workspace: kvc_workspace_bytes_batch(). */
+size_t kvc_workspace_bytes_batch(const kvc_params* p, int n_items, const int32_t* k_per_item);
+int kvc_compress_batch(const kvc_params* p, int n_items, const int32_t* k_per_item,
+                       const void* const* q, const void* const* k, const void* const* v,
+                       void* const* k_out, void* const* v_out, int64_t* const* idx_out, void* const* scores_out,
+                       void* workspace, size_t workspace_bytes, void* hip_stream);
+
 /* Stage entry points (same kernels kvc_compress enqueues), exposed so parity can be pinned stage by stage. */
 
 /* A1-A5 (A10 for H2O): pooled scores [bsz][n_q_heads][L-W] in dtype (:317-333 / :544-561). */

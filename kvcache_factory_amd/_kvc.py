@@ -19,7 +19,7 @@ POOLINGS = {"avgpool": POOL_AVG, "maxpool": POOL_MAX, None: POOL_NONE, "none": P
 TIE_MODES = {"torch_cpu": TIES_TORCH_CPU, "canonical": TIES_CANONICAL}
 
 EXPORTS = ("kvc_version", "kvc_last_error", "kvc_workspace_bytes", "kvc_compress", "kvc_scores", "kvc_select",
-           "kvc_gather", "kvc_pyramid_k", "kvc_workspace_layout")
+           "kvc_gather", "kvc_pyramid_k", "kvc_workspace_layout", "kvc_workspace_bytes_batch", "kvc_compress_batch")
 
 
 class KvcError(RuntimeError):
@@ -61,6 +61,9 @@ def lib():
         L.kvc_pyramid_k.argtypes = [ctypes.c_int64] * 6
         L.kvc_pyramid_k.restype = ctypes.c_int64
         L.kvc_workspace_layout.argtypes = [pp, ctypes.POINTER(sz * 3)]
+        L.kvc_workspace_bytes_batch.argtypes = [pp, ctypes.c_int, vp]
+        L.kvc_workspace_bytes_batch.restype = sz
+        L.kvc_compress_batch.argtypes = [pp, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         _lib = L
     return _lib
 
@@ -260,6 +263,50 @@ class CompressPlan:
 
     def run(self, stream=None):
         rc = self._fn(*self._args, stream if stream is not None else _stream(self.dev))
+        if rc:
+            _check(rc)
+        return self.k_out, self.v_out
+
+
+class BatchPlan:
+    """kvc_compress_batch over a list of (q, k, v) of identical shape — e.g. the layers of one prompt — with per-item
+    budgets.  Everything is resolved once; run() is one C call that enqueues each kernel once for all items."""
+
+    def __init__(self, method, qkv, window, n_keep, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu",
+                 want_indices=False):
+        n = len(qkv)
+        q0, k0, v0 = qkv[0]
+        _require_gpu(q0, k0, v0)
+        self.items = [(_last_dim_contig(q), _last_dim_contig(k), _last_dim_contig(v)) for q, k, v in qkv]
+        for q, k, v in self.items:
+            assert q.shape == q0.shape and k.shape == k0.shape and q.stride() == self.items[0][0].stride() and \
+                k.stride() == self.items[0][1].stride() and v.stride() == self.items[0][2].stride(), "items must share one layout"
+        keeps = list(n_keep) if hasattr(n_keep, "__len__") else [int(n_keep)] * n
+        q, k, v = self.items[0]
+        self.p = make_params(method, q, k, v, window, max(keeps), kernel_size, pooling, tie_mode)
+        dev = k.device
+        bsz, hq, D = k.shape[0], q.shape[1], k.shape[3]
+        self.k_out = [torch.empty(bsz, hq, kk + window, D, dtype=k.dtype, device=dev) for kk in keeps]
+        self.v_out = [torch.empty_like(t) for t in self.k_out]
+        self.idx = [torch.empty(bsz, hq, kk, dtype=torch.int64, device=dev) for kk in keeps] if want_indices else None
+        arr = ctypes.c_void_p * n
+        self._keep = (ctypes.c_int32 * n)(*keeps)
+        self._q = arr(*[t[0].data_ptr() for t in self.items])
+        self._k = arr(*[t[1].data_ptr() for t in self.items])
+        self._v = arr(*[t[2].data_ptr() for t in self.items])
+        self._ko = arr(*[t.data_ptr() for t in self.k_out])
+        self._vo = arr(*[t.data_ptr() for t in self.v_out])
+        self._ix = arr(*[t.data_ptr() for t in self.idx]) if want_indices else None
+        self.nbytes = lib().kvc_workspace_bytes_batch(ctypes.byref(self.p), n, self._keep)
+        if self.nbytes == 0:
+            raise KvcError(ERR_INVALID, lib().kvc_last_error().decode())
+        self.ws = workspace(dev, self.nbytes)
+        self.dev, self.n = dev, n
+
+    def run(self, stream=None):
+        rc = lib().kvc_compress_batch(ctypes.byref(self.p), self.n, self._keep, self._q, self._k, self._v, self._ko,
+                                      self._vo, self._ix, None, _ptr(self.ws), self.nbytes,
+                                      stream if stream is not None else _stream(self.dev))
         if rc:
             _check(rc)
         return self.k_out, self.v_out

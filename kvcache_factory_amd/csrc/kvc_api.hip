@@ -92,9 +92,7 @@ Layout carve(const kvc_params* p) {
         l.rowsum = off; off = align_up(off + heads * R * 4, 256);
         l.scores = off; off = align_up(off + heads * n * es, 256);
         l.idx = off;    off = align_up(off + heads * (size_t)p->k * 8, 256);
-        l.exact = off;
-        if (p->tie_mode == KVC_TIES_TORCH_CPU)
-            off = align_up(off + kvc::select_exact_scratch_bytes((int)heads, (int)n, p->k), 256);
+        l.exact = off;     // (the exact tie mode's scratch follows the per-item regions: exact_scratch_total)
     }
     l.total = off;
     return l;
@@ -114,32 +112,44 @@ int hip_ok(const char* where) {
     return KVC_OK;
 }
 
-int enqueue_scores(const kvc_params* p, const Layout& l, const void* q, const void* k, void* scores, char* ws, hipStream_t st) {
+// One "item" = one update_kv (one layer).  kvc_compress is the 1-item case of the batched entry point.
+struct Items {
+    int n;
+    const void* q[kvc::KVC_MAX_ITEMS]; const void* k[kvc::KVC_MAX_ITEMS]; const void* v[kvc::KVC_MAX_ITEMS];
+    void* k_out[kvc::KVC_MAX_ITEMS]; void* v_out[kvc::KVC_MAX_ITEMS];
+    void* scores[kvc::KVC_MAX_ITEMS]; int64_t* idx[kvc::KVC_MAX_ITEMS];
+    int keep[kvc::KVC_MAX_ITEMS];
+    int k_max;
+};
+
+// scores for every item (pointers in it.scores must be set).  Workspace of item i = ws + i * l.total.
+int enqueue_scores(const kvc_params* p, const Layout& l, const Items& it, char* ws, hipStream_t st) {
     if (p->method == KVC_H2O) {
-        kvc::H2OArgs h;
-        h.q = q; h.k = k;
-        h.S = ws + l.logits;
-        h.rowmax = reinterpret_cast<float*>(ws + l.rowmax);
-        h.rinv = reinterpret_cast<float*>(ws + l.rowsum);
-        h.scores = scores;
-        h.q_stride_b = p->q_stride_b; h.q_stride_h = p->q_stride_h; h.q_stride_l = p->q_stride_l;
-        h.k_stride_b = p->k_stride_b; h.k_stride_h = p->k_stride_h; h.k_stride_l = p->k_stride_l;
-        h.bsz = p->bsz; h.n_q_heads = p->n_q_heads; h.n_kv_heads = p->n_kv_heads; h.group = p->n_q_heads / p->n_kv_heads;
-        h.q_len = p->q_len; h.window = p->window;
-        h.sqrt_d = (float)std::sqrt((double)p->head_dim);
-        const int rc = kvc::launch_h2o_scores(h, p->dtype, p->head_dim, st);
-        if (rc) return fail(rc, "no H2O kernel for dtype %d head_dim %d", p->dtype, p->head_dim);
+        for (int i = 0; i < it.n; ++i) {
+            char* w = ws + (size_t)i * l.total;
+            kvc::H2OArgs h;
+            h.q = it.q[i]; h.k = it.k[i];
+            h.S = w + l.logits;
+            h.rowmax = reinterpret_cast<float*>(w + l.rowmax);
+            h.rinv = reinterpret_cast<float*>(w + l.rowsum);
+            h.scores = it.scores[i];
+            h.q_stride_b = p->q_stride_b; h.q_stride_h = p->q_stride_h; h.q_stride_l = p->q_stride_l;
+            h.k_stride_b = p->k_stride_b; h.k_stride_h = p->k_stride_h; h.k_stride_l = p->k_stride_l;
+            h.bsz = p->bsz; h.n_q_heads = p->n_q_heads; h.n_kv_heads = p->n_kv_heads; h.group = p->n_q_heads / p->n_kv_heads;
+            h.q_len = p->q_len; h.window = p->window;
+            h.sqrt_d = (float)std::sqrt((double)p->head_dim);
+            const int rc = kvc::launch_h2o_scores(h, p->dtype, p->head_dim, st);
+            if (rc) return fail(rc, "no H2O kernel for dtype %d head_dim %d", p->dtype, p->head_dim);
+        }
         return hip_ok("h2o scores launch");
     }
     kvc::ScoreArgs a;
-    a.q = q; a.k = k;
-    a.logits = ws + l.logits;
-    a.ebuf = reinterpret_cast<float*>(ws + l.ebuf);
-    a.pmax = reinterpret_cast<float*>(ws + l.pmax);
-    a.psum = reinterpret_cast<float*>(ws + l.psum);
-    a.rowmax = reinterpret_cast<float*>(ws + l.rowmax);
-    a.rowsum = reinterpret_cast<float*>(ws + l.rowsum);
-    a.scores = scores;
+    std::memset(&a, 0, sizeof(a));
+    for (int i = 0; i < it.n; ++i) { a.q.p[i] = it.q[i]; a.k.p[i] = it.k[i]; a.scores.p[i] = it.scores[i]; }
+    a.n_items = it.n;
+    a.ws = ws; a.ws_item_stride = (int64_t)l.total;
+    a.off_logits = (int64_t)l.logits; a.off_ebuf = (int64_t)l.ebuf; a.off_pmax = (int64_t)l.pmax;
+    a.off_psum = (int64_t)l.psum; a.off_rowmax = (int64_t)l.rowmax; a.off_rowsum = (int64_t)l.rowsum;
     a.q_stride_b = p->q_stride_b; a.q_stride_h = p->q_stride_h; a.q_stride_l = p->q_stride_l;
     a.k_stride_b = p->k_stride_b; a.k_stride_h = p->k_stride_h; a.k_stride_l = p->k_stride_l;
     a.bsz = p->bsz; a.n_q_heads = p->n_q_heads; a.n_kv_heads = p->n_kv_heads;
@@ -151,7 +161,7 @@ int enqueue_scores(const kvc_params* p, const Layout& l, const void* q, const vo
     a.nbuf = ((p->q_len + 31) / 32 + l.n_tiles * 4 - 1) / (l.n_tiles * 4) > 1 ? 2 : 1;
     a.dbg = nullptr;
 #if defined(KVC_STAMPS)
-    a.dbg = reinterpret_cast<unsigned long long*>(scores);   // diagnostic build: stamps land in scores_out
+    a.dbg = reinterpret_cast<unsigned long long*>(it.scores[0]);   // diagnostic build: stamps land in scores_out
 #endif
     a.sqrt_d = (float)std::sqrt((double)p->head_dim);   // math.sqrt(head_dim) -> fp32 (pyramidkv_utils.py:317)
     const int rc = kvc::launch_scores(a, p->dtype, p->head_dim, st);
@@ -159,30 +169,39 @@ int enqueue_scores(const kvc_params* p, const Layout& l, const void* q, const vo
     return hip_ok("scores launch");
 }
 
-kvc::GatherArgs gather_args(const kvc_params* p, const void* src, int64_t sb, int64_t sh, int64_t sl, const int64_t* idx, void* out) {
+// which: 0 = K (it.k -> it.k_out), 1 = V.  use_idx: gather through it.idx (else identity indices, StreamingLLM).
+kvc::GatherArgs gather_args(const kvc_params* p, const Items& it, int which, bool use_idx) {
     kvc::GatherArgs g;
-    g.src = src; g.out = out; g.idx = idx;
-    g.stride_b = sb; g.stride_h = sh; g.stride_l = sl;
+    std::memset(&g, 0, sizeof(g));
+    for (int i = 0; i < it.n; ++i) {
+        g.src.p[i] = which ? it.v[i] : it.k[i];
+        g.out.p[i] = which ? it.v_out[i] : it.k_out[i];
+        g.idx.p[i] = use_idx ? it.idx[i] : nullptr;
+        g.k.v[i] = it.keep[i];
+    }
+    g.n_items = it.n; g.k_max = it.k_max;
+    g.stride_b = which ? p->v_stride_b : p->k_stride_b;
+    g.stride_h = which ? p->v_stride_h : p->k_stride_h;
+    g.stride_l = which ? p->v_stride_l : p->k_stride_l;
     g.bsz = p->bsz; g.n_q_heads = p->n_q_heads; g.group = p->n_q_heads / p->n_kv_heads;
-    g.q_len = p->q_len; g.window = p->window; g.k = p->k;
+    g.q_len = p->q_len; g.window = p->window;
     g.esize = esize_of(p->dtype);
     g.row_bytes = p->head_dim * g.esize;
     return g;
 }
 
-// A7 (+ A8 in the same kernel when gk/gv are given and k is small).
-int enqueue_select(const kvc_params* p, const void* scores, int64_t* idx, const kvc::GatherArgs* gk, const kvc::GatherArgs* gv,
-                   void* exact_scratch, hipStream_t st) {
-    if (p->k == 0) return KVC_OK;
-    if (p->k > 16384) return fail(KVC_ERR_UNSUPPORTED, "k=%d > 16384: the LDS sort of the selected set is not built for it", p->k);
+// A7 for every item (+ A8 in the same kernel when `fuse`).  exact_scratch: n_items regions for the exact tie mode.
+int enqueue_select(const kvc_params* p, const Items& it, bool fuse, void* exact_scratch, hipStream_t st) {
+    if (it.k_max > 16384) return fail(KVC_ERR_UNSUPPORTED, "k=%d > 16384: the LDS sort of the selected set is not built for it", it.k_max);
     if (p->q_len - p->window > 65536) return fail(KVC_ERR_UNSUPPORTED, "more than 65536 candidates per head not built");
     kvc::SelectArgs s;
     std::memset(&s, 0, sizeof(s));
-    s.scores = scores; s.idx = idx;
-    s.n = p->q_len - p->window; s.k = p->k; s.heads = p->bsz * p->n_q_heads;
+    for (int i = 0; i < it.n; ++i) { s.scores.p[i] = it.scores[i]; s.idx.p[i] = it.idx[i]; s.k.v[i] = it.keep[i]; }
+    s.n_items = it.n;
+    s.n = p->q_len - p->window; s.k_max = it.k_max; s.heads = p->bsz * p->n_q_heads;
     s.pow2 = 1;
-    while (s.pow2 < s.k) s.pow2 <<= 1;
-    if (gk && gv) { s.fuse = 1; s.gk = *gk; s.gv = *gv; }
+    while (s.pow2 < s.k_max) s.pow2 <<= 1;
+    if (fuse) { s.fuse = 1; s.gk = gather_args(p, it, 0, true); s.gv = gather_args(p, it, 1, true); }
     if (p->tie_mode == KVC_TIES_TORCH_CPU) {
         const int rc = kvc::launch_select_exact(s, p->dtype, exact_scratch, st);
         if (rc == KVC_ERR_WORKSPACE) return fail(rc, "tie_mode torch_cpu at n=%d needs the workspace (kvc_workspace_bytes)", s.n);
@@ -204,6 +223,71 @@ int enqueue_gather(const kvc::GatherArgs* g0, const kvc::GatherArgs* g1, hipStre
     return hip_ok("gather launch");
 }
 
+// Bytes of the (shared, after the per-item regions) scratch the exact tie mode needs for all items.
+size_t exact_scratch_total(const kvc_params* p, int n_items, const int* keep) {
+    if (p->tie_mode != KVC_TIES_TORCH_CPU || !scoring(p->method)) return 0;
+    size_t worst = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const size_t b = kvc::select_exact_scratch_bytes(p->bsz * p->n_q_heads, p->q_len - p->window, keep[i]);
+        if (b > worst) worst = b;
+    }
+    return align_up(worst * (size_t)n_items, 256);
+}
+
+// The whole pipeline for it.n items of identical shape (p) and per-item k.
+int run_items(const kvc_params* p, Items& it, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    const int es = esize_of(p->dtype);
+    if (int rc = check_strides("k", es, p->k_stride_b, p->k_stride_h, p->k_stride_l, it.k[0])) return rc;
+    if (int rc = check_strides("v", es, p->v_stride_b, p->v_stride_h, p->v_stride_l, it.v[0])) return rc;
+    it.k_max = 0;
+    for (int i = 0; i < it.n; ++i) {
+        if (!it.k[i] || !it.v[i] || !it.k_out[i] || !it.v_out[i]) return fail(KVC_ERR_INVALID, "k, v, k_out and v_out must be non-NULL (item %d)", i);
+        if (((uintptr_t)it.k[i]) % 16 || ((uintptr_t)it.v[i]) % 16 || ((uintptr_t)it.k_out[i]) % 16 || ((uintptr_t)it.v_out[i]) % 16)
+            return fail(KVC_ERR_ALIGNMENT, "k / v / k_out / v_out not 16-byte aligned (item %d)", i);
+        if (it.keep[i] < 0 || it.keep[i] > p->q_len - p->window) return fail(KVC_ERR_INVALID, "k=%d outside [0, q_len-window] (item %d)", it.keep[i], i);
+        if (it.keep[i] > it.k_max) it.k_max = it.keep[i];
+    }
+    if (!scoring(p->method)) {
+        for (int i = 0; i < it.n; ++i)
+            if (it.idx[i] && it.keep[i] > 0)
+                return fail(KVC_ERR_UNSUPPORTED, "StreamingLLM: idx_out must be NULL (indices are arange(k), pyramidkv_utils.py:607)");
+        const kvc::GatherArgs gk = gather_args(p, it, 0, false), gv = gather_args(p, it, 1, false);
+        return enqueue_gather(&gk, &gv, st);
+    }
+    kvc_params pk = *p;
+    pk.k = it.k_max;
+    const Layout l = carve(&pk);
+    const size_t exact = exact_scratch_total(p, it.n, it.keep);
+    const size_t need = l.total * (size_t)it.n + exact;
+    if (!workspace) return fail(KVC_ERR_WORKSPACE, "workspace is NULL, need %zu bytes", need);
+    if (((uintptr_t)workspace) % 256) return fail(KVC_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    if (workspace_bytes < need) return fail(KVC_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, need);
+    char* ws = static_cast<char*>(workspace);
+    bool any_zero = false;
+    for (int i = 0; i < it.n; ++i) {
+        if (!it.q[i]) return fail(KVC_ERR_INVALID, "q must be non-NULL for scoring methods (item %d)", i);
+        if (((uintptr_t)it.q[i]) % 16) return fail(KVC_ERR_ALIGNMENT, "q pointer not 16-byte aligned (item %d)", i);
+        if (it.idx[i] && ((uintptr_t)it.idx[i]) % 16) return fail(KVC_ERR_ALIGNMENT, "idx_out not 16-byte aligned");
+        if (it.scores[i] && ((uintptr_t)it.scores[i]) % 16) return fail(KVC_ERR_ALIGNMENT, "scores_out not 16-byte aligned");
+        char* w = ws + (size_t)i * l.total;
+        if (!it.scores[i]) it.scores[i] = w + l.scores;
+        if (!it.idx[i]) it.idx[i] = reinterpret_cast<int64_t*>(w + l.idx);
+        any_zero = any_zero || it.keep[i] == 0;
+    }
+    if (int rc = check_strides("q", es, p->q_stride_b, p->q_stride_h, p->q_stride_l, it.q[0])) return rc;
+    if (any_zero && it.n > 1) return fail(KVC_ERR_UNSUPPORTED, "a batch needs k >= 1 for every item");
+    if (int rc = enqueue_scores(p, l, it, ws, st)) return rc;
+    if (it.k_max == 0) {                                     // nothing to select: only the window tail is kept
+        const kvc::GatherArgs gk = gather_args(p, it, 0, false), gv = gather_args(p, it, 1, false);
+        return enqueue_gather(&gk, &gv, st);
+    }
+    const bool fuse = it.k_max <= kvc::kFuseGatherMaxK && p->tie_mode == KVC_TIES_CANONICAL;
+    if (int rc = enqueue_select(p, it, fuse, ws + l.total * (size_t)it.n, st)) return rc;
+    if (fuse) return KVC_OK;
+    const kvc::GatherArgs gk = gather_args(p, it, 0, true), gv = gather_args(p, it, 1, true);
+    return enqueue_gather(&gk, &gv, st);
+}
+
 }  // namespace
 
 extern "C" {
@@ -215,7 +299,20 @@ __attribute__((visibility("default"))) const char* kvc_last_error(void) { return
 __attribute__((visibility("default"))) size_t kvc_workspace_bytes(const kvc_params* p) {
     if (validate(p, true) != KVC_OK) return 0;
     g_err[0] = 0;
-    return carve(p).total;
+    return carve(p).total + exact_scratch_total(p, 1, &p->k);
+}
+
+__attribute__((visibility("default"))) size_t kvc_workspace_bytes_batch(const kvc_params* p, int n_items, const int32_t* k_per_item) {
+    if (validate(p, true) != KVC_OK) return 0;
+    if (n_items < 1 || n_items > kvc::KVC_MAX_ITEMS || !k_per_item) { fail(KVC_ERR_INVALID, "n_items must be in [1, %d]", kvc::KVC_MAX_ITEMS); return 0; }
+    kvc_params pk = *p;
+    pk.k = 0;
+    for (int i = 0; i < n_items; ++i) {
+        if (k_per_item[i] < 0 || k_per_item[i] > p->q_len - p->window) { fail(KVC_ERR_INVALID, "k=%d out of range (item %d)", k_per_item[i], i); return 0; }
+        if (k_per_item[i] > pk.k) pk.k = k_per_item[i];
+    }
+    g_err[0] = 0;
+    return carve(&pk).total * (size_t)n_items + exact_scratch_total(p, n_items, k_per_item);
 }
 
 __attribute__((visibility("default"))) int kvc_workspace_layout(const kvc_params* p, size_t offs[3]) {
@@ -252,7 +349,10 @@ __attribute__((visibility("default"))) int kvc_scores(const kvc_params* p, const
     if (((uintptr_t)scores_out) % 16) return fail(KVC_ERR_ALIGNMENT, "scores_out not 16-byte aligned");
     const Layout l = carve(p);
     if (int rc = check_ws(l, workspace, workspace_bytes)) return rc;
-    return enqueue_scores(p, l, q, k, scores_out, static_cast<char*>(workspace), static_cast<hipStream_t>(hip_stream));
+    Items it;
+    std::memset(&it, 0, sizeof(it));
+    it.n = 1; it.q[0] = q; it.k[0] = k; it.scores[0] = scores_out;
+    return enqueue_scores(p, l, it, static_cast<char*>(workspace), static_cast<hipStream_t>(hip_stream));
 }
 
 __attribute__((visibility("default"))) int kvc_select(const kvc_params* p, const void* scores, int64_t* idx_out,
@@ -260,6 +360,7 @@ __attribute__((visibility("default"))) int kvc_select(const kvc_params* p, const
     if (int rc = validate(p, false)) return rc;
     if (!scores || !idx_out) return fail(KVC_ERR_INVALID, "scores and idx_out must be non-NULL");
     if (((uintptr_t)scores) % 16 || ((uintptr_t)idx_out) % 16) return fail(KVC_ERR_ALIGNMENT, "scores / idx_out not 16-byte aligned");
+    if (p->k == 0) return KVC_OK;
     void* scratch = nullptr;
     if (p->tie_mode == KVC_TIES_TORCH_CPU) {
         const size_t need = kvc::select_exact_scratch_bytes(p->bsz * p->n_q_heads, p->q_len - p->window, p->k);
@@ -269,7 +370,10 @@ __attribute__((visibility("default"))) int kvc_select(const kvc_params* p, const
             scratch = workspace;
         }
     }
-    return enqueue_select(p, scores, idx_out, nullptr, nullptr, scratch, static_cast<hipStream_t>(hip_stream));
+    Items it;
+    std::memset(&it, 0, sizeof(it));
+    it.n = 1; it.scores[0] = const_cast<void*>(scores); it.idx[0] = idx_out; it.keep[0] = p->k; it.k_max = p->k;
+    return enqueue_select(p, it, false, scratch, static_cast<hipStream_t>(hip_stream));
 }
 
 __attribute__((visibility("default"))) int kvc_gather(const kvc_params* p, const void* src, int64_t stride_b, int64_t stride_h,
@@ -278,7 +382,12 @@ __attribute__((visibility("default"))) int kvc_gather(const kvc_params* p, const
     if (!src || !out) return fail(KVC_ERR_INVALID, "src and out must be non-NULL");
     if (int rc = check_strides("src", esize_of(p->dtype), stride_b, stride_h, stride_l, src)) return rc;
     if (((uintptr_t)out) % 16) return fail(KVC_ERR_ALIGNMENT, "out not 16-byte aligned");
-    const kvc::GatherArgs g = gather_args(p, src, stride_b, stride_h, stride_l, idx, out);
+    Items it;
+    std::memset(&it, 0, sizeof(it));
+    it.n = 1; it.k[0] = src; it.k_out[0] = out; it.idx[0] = const_cast<int64_t*>(idx); it.keep[0] = p->k; it.k_max = p->k;
+    kvc_params ps = *p;
+    ps.k_stride_b = stride_b; ps.k_stride_h = stride_h; ps.k_stride_l = stride_l;
+    const kvc::GatherArgs g = gather_args(&ps, it, 0, idx != nullptr);
     return enqueue_gather(&g, nullptr, static_cast<hipStream_t>(hip_stream));
 }
 
@@ -287,33 +396,39 @@ __attribute__((visibility("default"))) int kvc_compress(const kvc_params* p, con
                                                         void* workspace, size_t workspace_bytes, void* hip_stream) {
     if (int rc = validate(p, true)) return rc;
     if (p->debug_stage_mask != 0) return fail(KVC_ERR_INVALID, "debug_stage_mask is only honoured by kvc_scores");
-    if (!k || !v || !k_out || !v_out) return fail(KVC_ERR_INVALID, "k, v, k_out and v_out must be non-NULL");
-    const int es = esize_of(p->dtype);
-    if (int rc = check_strides("k", es, p->k_stride_b, p->k_stride_h, p->k_stride_l, k)) return rc;
-    if (int rc = check_strides("v", es, p->v_stride_b, p->v_stride_h, p->v_stride_l, v)) return rc;
-    if (((uintptr_t)k_out) % 16 || ((uintptr_t)v_out) % 16) return fail(KVC_ERR_ALIGNMENT, "k_out / v_out not 16-byte aligned");
+    Items it;
+    std::memset(&it, 0, sizeof(it));
+    it.n = 1;
+    it.q[0] = q; it.k[0] = k; it.v[0] = v; it.k_out[0] = k_out; it.v_out[0] = v_out;
+    it.idx[0] = idx_out; it.scores[0] = scores_out; it.keep[0] = p->k;
+    return run_items(p, it, workspace, workspace_bytes, static_cast<hipStream_t>(hip_stream));
+}
+
+__attribute__((visibility("default"))) int kvc_compress_batch(const kvc_params* p, int n_items, const int32_t* k_per_item,
+                                                              const void* const* q, const void* const* k, const void* const* v,
+                                                              void* const* k_out, void* const* v_out, int64_t* const* idx_out,
+                                                              void* const* scores_out, void* workspace, size_t workspace_bytes,
+                                                              void* hip_stream) {
+    if (int rc = validate(p, true)) return rc;
+    if (p->debug_stage_mask != 0) return fail(KVC_ERR_INVALID, "debug_stage_mask is only honoured by kvc_scores");
+    if (n_items < 1 || !k_per_item || !k || !v || !k_out || !v_out) return fail(KVC_ERR_INVALID, "n_items >= 1 and the pointer arrays must be non-NULL");
+    if (scoring(p->method) && !q) return fail(KVC_ERR_INVALID, "q array must be non-NULL for scoring methods");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    kvc::GatherArgs gk = gather_args(p, k, p->k_stride_b, p->k_stride_h, p->k_stride_l, nullptr, k_out);
-    kvc::GatherArgs gv = gather_args(p, v, p->v_stride_b, p->v_stride_h, p->v_stride_l, nullptr, v_out);
-    if (scoring(p->method)) {
-        if (!q) return fail(KVC_ERR_INVALID, "q must be non-NULL for scoring methods");
-        if (int rc = check_strides("q", es, p->q_stride_b, p->q_stride_h, p->q_stride_l, q)) return rc;
-        if (idx_out && ((uintptr_t)idx_out) % 16) return fail(KVC_ERR_ALIGNMENT, "idx_out not 16-byte aligned");
-        if (scores_out && ((uintptr_t)scores_out) % 16) return fail(KVC_ERR_ALIGNMENT, "scores_out not 16-byte aligned");
-        const Layout l = carve(p);
-        if (int rc = check_ws(l, workspace, workspace_bytes)) return rc;
-        char* ws = static_cast<char*>(workspace);
-        void* sc = scores_out ? scores_out : static_cast<void*>(ws + l.scores);
-        int64_t* ix = idx_out ? idx_out : reinterpret_cast<int64_t*>(ws + l.idx);
-        if (int rc = enqueue_scores(p, l, q, k, sc, ws, st)) return rc;
-        const bool fuse = p->k > 0 && p->k <= kvc::kFuseGatherMaxK && p->tie_mode == KVC_TIES_CANONICAL;
-        if (int rc = enqueue_select(p, sc, ix, fuse ? &gk : nullptr, fuse ? &gv : nullptr, ws + l.exact, st)) return rc;
-        if (fuse) return KVC_OK;
-        gk.idx = gv.idx = ix;
-    } else if (idx_out && p->k > 0) {
-        return fail(KVC_ERR_UNSUPPORTED, "StreamingLLM: idx_out must be NULL (indices are arange(k), pyramidkv_utils.py:607)");
+    // chunks of KVC_MAX_ITEMS items share one launch of each kernel; each chunk uses the same workspace (stream-ordered)
+    for (int base = 0; base < n_items; base += kvc::KVC_MAX_ITEMS) {
+        Items it;
+        std::memset(&it, 0, sizeof(it));
+        it.n = n_items - base < kvc::KVC_MAX_ITEMS ? n_items - base : kvc::KVC_MAX_ITEMS;
+        for (int i = 0; i < it.n; ++i) {
+            it.q[i] = q ? q[base + i] : nullptr; it.k[i] = k[base + i]; it.v[i] = v[base + i];
+            it.k_out[i] = k_out[base + i]; it.v_out[i] = v_out[base + i];
+            it.idx[i] = idx_out ? idx_out[base + i] : nullptr;
+            it.scores[i] = scores_out ? scores_out[base + i] : nullptr;
+            it.keep[i] = k_per_item[base + i];
+        }
+        if (int rc = run_items(p, it, workspace, workspace_bytes, st)) return rc;
     }
-    return enqueue_gather(&gk, &gv, st);
+    return KVC_OK;
 }
 
 }  // extern "C"

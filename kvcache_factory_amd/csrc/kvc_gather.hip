@@ -8,21 +8,24 @@
 namespace kvc {
 
 __global__ __launch_bounds__(256) void gather_kernel(const GatherPair pr) {
-    const GatherArgs& a = pr.t[blockIdx.z];
+    const int which = blockIdx.z % pr.count, item = blockIdx.z / pr.count;
+    const GatherArgs& a = pr.t[which];
+    const int k = a.k.v[item];
     const int lanes_per_row = a.row_bytes >> 4;
     const int rows_per_block = 256 / lanes_per_row;
     const int r = threadIdx.x / lanes_per_row, c = threadIdx.x % lanes_per_row;
-    const int cap = a.k + a.window;
+    const int cap = k + a.window;
     const int t = blockIdx.x * rows_per_block + r;
     if (r >= rows_per_block || t >= cap) return;
     const int hb = blockIdx.y, b = hb / a.n_q_heads, h = hb % a.n_q_heads;
     int64_t srow;
-    if (t < a.k) srow = a.idx ? a.idx[(int64_t)hb * a.k + t] : (int64_t)t;
-    else srow = (int64_t)(a.q_len - a.window) + (t - a.k);
+    const int64_t* idx = reinterpret_cast<const int64_t*>(a.idx.p[item]);
+    if (t < k) srow = idx ? idx[(int64_t)hb * k + t] : (int64_t)t;
+    else srow = (int64_t)(a.q_len - a.window) + (t - k);
     const int64_t esz = a.esize;
-    const char* src = reinterpret_cast<const char*>(a.src) +
+    const char* src = reinterpret_cast<const char*>(a.src.p[item]) +
         ((int64_t)b * a.stride_b + (int64_t)(h / a.group) * a.stride_h + srow * a.stride_l) * esz + c * 16;
-    char* dst = reinterpret_cast<char*>(a.out) + ((int64_t)hb * cap + t) * a.row_bytes + c * 16;
+    char* dst = reinterpret_cast<char*>(const_cast<void*>(a.out.p[item])) + ((int64_t)hb * cap + t) * a.row_bytes + c * 16;
     *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
 }
 
@@ -30,8 +33,8 @@ int launch_gather(const GatherPair& p, hipStream_t st) {
     const GatherArgs& a = p.t[0];
     const int lanes_per_row = a.row_bytes / 16;
     const int rows_per_block = 256 / lanes_per_row;
-    const int cap = a.k + a.window;
-    dim3 grid((unsigned)((cap + rows_per_block - 1) / rows_per_block), (unsigned)(a.bsz * a.n_q_heads), (unsigned)p.count);
+    const int cap = a.k_max + a.window;
+    dim3 grid((unsigned)((cap + rows_per_block - 1) / rows_per_block), (unsigned)(a.bsz * a.n_q_heads), (unsigned)(p.count * a.n_items));
     hipLaunchKernelGGL(gather_kernel, grid, dim3(256), 0, st, p);
     return 0;
 }

@@ -5,15 +5,30 @@
 
 namespace kvc {
 
-struct ScoreArgs {
+// One launch of every kernel can serve up to KVC_MAX_ITEMS independent "items" (the layers of one prompt:
+// kvc_compress_batch) — same shapes, per-item tensors and per-item k.  Pointer tables travel in the kernel arguments
+// (no device-side copies); blockIdx.z (or .y for the per-head kernels) is the item.  kvc_compress is the 1-item case.
+constexpr int KVC_MAX_ITEMS = 32;
+struct PtrTable { const void* p[KVC_MAX_ITEMS]; };
+struct IntTable { int v[KVC_MAX_ITEMS]; };
+
+struct ScoreView {         // one item's pointers, resolved at kernel entry
     const void* q; const void* k;
-    void* logits;          // [bsz*Hq][L][W] dtype
-    float* ebuf;           // [bsz*Hq][L][W] fp32: exp(logit - rowmax), written by rowsum_kernel, read by pool_kernel
-    float* pmax;           // [bsz*Hq][n_tiles][W]
-    float* psum;           // [bsz*Hq][n_chunks][W]
-    float* rowmax;         // [bsz*Hq][W]
-    float* rowsum;         // [bsz*Hq][W]
-    void* scores;          // [bsz*Hq][L-W] dtype
+    void* logits; float* ebuf; float* pmax; float* psum; float* rowmax; float* rowsum; void* scores;
+};
+
+struct ScoreArgs {
+    PtrTable q, k, scores; // per item; scores [bsz*Hq][L-W] dtype
+    char* ws;              // workspace of item 0; item i lives ws_item_stride bytes further
+    int64_t ws_item_stride;
+    // byte offsets inside an item's workspace:
+    int64_t off_logits;    // [bsz*Hq][L][W] dtype
+    int64_t off_ebuf;      // [bsz*Hq][L][W] fp32: exp(logit - rowmax), written by rowsum_kernel, read by pool_kernel
+    int64_t off_pmax;      // [bsz*Hq][n_tiles][W] fp32
+    int64_t off_psum;      // [bsz*Hq][n_chunks][W] fp32
+    int64_t off_rowmax;    // [bsz*Hq][W] fp32
+    int64_t off_rowsum;    // [bsz*Hq][W] fp32
+    int n_items;
     int64_t q_stride_b, q_stride_h, q_stride_l;
     int64_t k_stride_b, k_stride_h, k_stride_l;
     int bsz, n_q_heads, n_kv_heads, group, q_len, window;
@@ -37,16 +52,19 @@ struct H2OArgs {
 };
 
 struct GatherArgs {
-    const void* src; void* out; const int64_t* idx;   // idx may be null (identity)
+    PtrTable src, out, idx;                           // per item; idx entry may be null (identity)
+    IntTable k;                                       // per item
     int64_t stride_b, stride_h, stride_l;             // elements
-    int bsz, n_q_heads, group, q_len, window, k, row_bytes, esize;
+    int bsz, n_q_heads, group, q_len, window, k_max, row_bytes, esize, n_items;
 };
 
 struct SelectArgs {
-    const void* scores;    // [bsz*Hq][n] dtype
-    int64_t* idx;          // [bsz*Hq][k]
-    int n, k, heads;       // heads = bsz*Hq
-    int pow2;              // next power of two >= k
+    PtrTable scores;       // per item: [bsz*Hq][n] dtype
+    PtrTable idx;          // per item: int64 [bsz*Hq][k_item]
+    IntTable k;            // per item
+    int n, k_max, heads;   // heads = bsz*Hq
+    int n_items;
+    int pow2;              // next power of two >= k_max
     int fuse;              // 1: also gather K (gk) and V (gv) rows of the head in the same workgroup
     GatherArgs gk, gv;
 };
@@ -58,7 +76,7 @@ int launch_h2o_scores(const H2OArgs& a, int dtype, int head_dim, hipStream_t st)
 int launch_select(const SelectArgs& a, int dtype, int tie_mode, hipStream_t st);
 size_t select_lds_bytes(int k);
 int launch_select_exact(const SelectArgs& a, int dtype, void* scratch, hipStream_t st);   // tie_mode torch_cpu
-size_t select_exact_scratch_bytes(int heads, int n, int k);
+size_t select_exact_scratch_bytes(int heads, int n, int k);     // per item
 int launch_gather(const GatherPair& p, hipStream_t st);
 static constexpr int kFuseGatherMaxK = 512;   // select_kernel gathers the rows itself up to this k
 

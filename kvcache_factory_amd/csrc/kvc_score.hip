@@ -22,6 +22,19 @@ namespace kvc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+__device__ __forceinline__ ScoreView view_of(const ScoreArgs& a, int item) {
+    char* w = a.ws + (int64_t)item * a.ws_item_stride;
+    ScoreView v;
+    v.q = a.q.p[item]; v.k = a.k.p[item]; v.scores = const_cast<void*>(a.scores.p[item]);
+    v.logits = w + a.off_logits;
+    v.ebuf = reinterpret_cast<float*>(w + a.off_ebuf);
+    v.pmax = reinterpret_cast<float*>(w + a.off_pmax);
+    v.psum = reinterpret_cast<float*>(w + a.off_psum);
+    v.rowmax = reinterpret_cast<float*>(w + a.off_rowmax);
+    v.rowsum = reinterpret_cast<float*>(w + a.off_rowsum);
+    return v;
+}
+
 // Diagnostic build only (-DKVC_STAMPS): per-wave s_memtime stamps at phase boundaries of logits_kernel, written to
 // a buffer of their own (ScoreArgs::dbg) that nothing else reads.  Never enabled in the shipped library.
 #if defined(KVC_STAMPS)
@@ -88,6 +101,7 @@ template <> struct ScaleDiv<128> {
 
 template <int DT, int D, int WV>
 __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
+    const ScoreView vw = view_of(a, blockIdx.z);
     typedef typename Dt<DT>::raw raw;
     constexpr int ES = Dt<DT>::esize;
     constexpr int ROWB = D * ES;             // bytes per key row
@@ -117,7 +131,7 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
     const float sqrt_d = a.sqrt_d;
     KVC_STAMP(0);
 
-    const char* kbase = reinterpret_cast<const char*>(a.k) +
+    const char* kbase = reinterpret_cast<const char*>(vw.k) +
                         ((int64_t)b * a.k_stride_b + (int64_t)g * a.k_stride_h) * ES;
     // chunk ids of this lane inside a tile: c = it*64 + lane -> row c / CH, chunk c % CH
     auto issue = [&](int tile, uint4 (&st)[STG]) {
@@ -153,7 +167,7 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (i < rows) {
                     const int hq = g * G + i / W, w = i % W;
-                    const char* qrow = reinterpret_cast<const char*>(a.q) +
+                    const char* qrow = reinterpret_cast<const char*>(vw.q) +
                         ((int64_t)b * a.q_stride_b + (int64_t)hq * a.q_stride_h + (int64_t)(L - W + w) * a.q_stride_l) * ES;
                     v = *reinterpret_cast<const uint4*>(qrow + cc * 16);
                 }
@@ -218,7 +232,7 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
                 if (i0 < rows && key < L) {
                     if ((W % 4) == 0) {
                         const int hq = g * G + i0 / W, w0 = i0 % W;
-                        raw* dst = reinterpret_cast<raw*>(a.logits) + (((int64_t)b * a.n_q_heads + hq) * L + key) * W + w0;
+                        raw* dst = reinterpret_cast<raw*>(vw.logits) + (((int64_t)b * a.n_q_heads + hq) * L + key) * W + w0;
                         if constexpr (ES == 2) {
                             uint2 pk;
                             pk.x = (uint32_t)Dt<DT>::st(x[0]) | ((uint32_t)Dt<DT>::st(x[1]) << 16);
@@ -233,7 +247,7 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
                             const int i = i0 + e;
                             if (i < rows) {
                                 const int hq = g * G + i / W, w = i % W;
-                                reinterpret_cast<raw*>(a.logits)[(((int64_t)b * a.n_q_heads + hq) * L + key) * W + w] = Dt<DT>::st(x[e]);
+                                reinterpret_cast<raw*>(vw.logits)[(((int64_t)b * a.n_q_heads + hq) * L + key) * W + w] = Dt<DT>::st(x[e]);
                             }
                         }
                     }
@@ -284,7 +298,7 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
 #pragma unroll
                 for (int wv = 1; wv < 4; ++wv) { const float o = wmax[wv * 32 + tid]; m = o > m ? o : m; }
                 const int hq = g * G + i / W, w = i % W;
-                a.pmax[(((int64_t)b * a.n_q_heads + hq) * a.n_tiles + blockIdx.x) * W + w] = m;
+                vw.pmax[(((int64_t)b * a.n_q_heads + hq) * a.n_tiles + blockIdx.x) * W + w] = m;
             }
         }
         __syncthreads();
@@ -345,6 +359,7 @@ __device__ __forceinline__ void load_logits(const typename Dt<DT>::raw* src, int
 // ---------------------------------------------------------------------------------------------
 template <int DT, int WV>
 __global__ __launch_bounds__(256) void rowsum_kernel(const ScoreArgs a) {
+    const ScoreView vw = view_of(a, blockIdx.z);
     typedef typename Dt<DT>::raw raw;
     __shared__ float m[64];
     __shared__ float scratch[256];
@@ -352,13 +367,13 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const ScoreArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int chunk = blockIdx.x, hb = blockIdx.y;
     const int L = a.q_len, W = WV > 0 ? WV : a.window;
-    block_row_max(a.pmax + (int64_t)hb * a.n_tiles * W, a.n_tiles, W, m, scratch);
-    if (chunk == 0 && tid < W) a.rowmax[(int64_t)hb * W + tid] = m[tid];
+    block_row_max(vw.pmax + (int64_t)hb * a.n_tiles * W, a.n_tiles, W, m, scratch);
+    if (chunk == 0 && tid < W) vw.rowmax[(int64_t)hb * W + tid] = m[tid];
 
     const int key = chunk * 256 + tid;
     float x[WV > 0 ? WV : 64];
-    if (key < L) load_logits<DT, WV>(reinterpret_cast<const raw*>(a.logits) + ((int64_t)hb * L + key) * W, W, x);
-    float* const erow = a.ebuf + ((int64_t)hb * L + (key < L ? key : 0)) * W;       // e = exp(x - max), kept for pool_kernel
+    if (key < L) load_logits<DT, WV>(reinterpret_cast<const raw*>(vw.logits) + ((int64_t)hb * L + key) * W, W, x);
+    float* const erow = vw.ebuf + ((int64_t)hb * L + (key < L ? key : 0)) * W;       // e = exp(x - max), kept for pool_kernel
 #pragma unroll
     for (int w = 0; w < (WV > 0 ? WV : W); ++w) {
         float e = (key < L) ? exp_u20(x[w] - m[w]) : 0.0f;
@@ -377,7 +392,7 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const ScoreArgs a) {
     __syncthreads();
     if (tid < W) {
         const float s = ((wsum[tid] + wsum[64 + tid]) + wsum[128 + tid]) + wsum[192 + tid];
-        a.psum[((int64_t)hb * a.n_chunks + chunk) * W + tid] = s;
+        vw.psum[((int64_t)hb * a.n_chunks + chunk) * W + tid] = s;
     }
 }
 
@@ -386,6 +401,7 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const ScoreArgs a) {
 // ---------------------------------------------------------------------------------------------
 template <int DT, int WV>
 __global__ __launch_bounds__(256) void pool_kernel(const ScoreArgs a) {
+    const ScoreView vw = view_of(a, blockIdx.z);
     typedef typename Dt<DT>::raw raw;
     __shared__ float m[64];
     __shared__ float rinv[64];
@@ -403,16 +419,16 @@ __global__ __launch_bounds__(256) void pool_kernel(const ScoreArgs a) {
         const int per_round = 320 / W;                       // chunks per round
         for (int c0 = 0; c0 < a.n_chunks; c0 += per_round) {
             const int cn = a.n_chunks - c0 < per_round ? a.n_chunks - c0 : per_round;
-            for (int t = tid; t < cn * W; t += 256) stage[t] = a.psum[((int64_t)hb * a.n_chunks + c0) * W + t];
+            for (int t = tid; t < cn * W; t += 256) stage[t] = vw.psum[((int64_t)hb * a.n_chunks + c0) * W + t];
             __syncthreads();
             if (tid < W)
                 for (int c = 0; c < cn; ++c) { const float v = stage[c * W + tid]; run = (c0 + c) == 0 ? v : run + v; }
             __syncthreads();
         }
         if (tid < W) {
-            m[tid] = a.rowmax[(int64_t)hb * W + tid];
+            m[tid] = vw.rowmax[(int64_t)hb * W + tid];
             rinv[tid] = 1.0f / run;
-            if (blockIdx.x == 0) a.rowsum[(int64_t)hb * W + tid] = run;
+            if (blockIdx.x == 0) vw.rowsum[(int64_t)hb * W + tid] = run;
         }
     }
     __syncthreads();
@@ -422,7 +438,7 @@ __global__ __launch_bounds__(256) void pool_kernel(const ScoreArgs a) {
         float sv = 0.0f;
         if (key >= 0 && key < n) {
             float x[WV > 0 ? WV : 64];
-            const float* erow = a.ebuf + ((int64_t)hb * L + key) * W;
+            const float* erow = vw.ebuf + ((int64_t)hb * L + key) * W;
             if constexpr (WV > 0) {
 #pragma unroll
                 for (int c = 0; c < WV / 4; ++c) {
@@ -459,7 +475,7 @@ __global__ __launch_bounds__(256) void pool_kernel(const ScoreArgs a) {
                 c = rnd<DT>(acc / (float)a.kernel_size);
             }
         }
-        reinterpret_cast<raw*>(a.scores)[(int64_t)hb * n + jo] = Dt<DT>::st(c);
+        reinterpret_cast<raw*>(vw.scores)[(int64_t)hb * n + jo] = Dt<DT>::st(c);
     }
 }
 
@@ -469,10 +485,10 @@ __global__ __launch_bounds__(256) void pool_kernel(const ScoreArgs a) {
 template <int DT, int WV>
 static void launch_softmax_pool_t(const ScoreArgs& a, hipStream_t st) {
     const int m = a.stage_mask ? a.stage_mask : 7;
-    dim3 g2((unsigned)a.n_chunks, (unsigned)(a.bsz * a.n_q_heads));
+    dim3 g2((unsigned)a.n_chunks, (unsigned)(a.bsz * a.n_q_heads), (unsigned)a.n_items);
     if (m & 2) hipLaunchKernelGGL((rowsum_kernel<DT, WV>), g2, dim3(256), 0, st, a);
     const int n = a.q_len - a.window;
-    dim3 g3((unsigned)((n + 255) / 256), (unsigned)(a.bsz * a.n_q_heads));
+    dim3 g3((unsigned)((n + 255) / 256), (unsigned)(a.bsz * a.n_q_heads), (unsigned)a.n_items);
     if (m & 4) hipLaunchKernelGGL((pool_kernel<DT, WV>), g3, dim3(256), 0, st, a);
 }
 
@@ -486,7 +502,7 @@ static void launch_all_t(const ScoreArgs& a, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_ok = lds;
     }
-    dim3 g1((unsigned)a.n_tiles, (unsigned)(a.bsz * a.n_kv_heads));
+    dim3 g1((unsigned)a.n_tiles, (unsigned)(a.bsz * a.n_kv_heads), (unsigned)a.n_items);
     if ((a.stage_mask ? a.stage_mask : 7) & 1) hipLaunchKernelGGL((logits_kernel<DT, D, WV>), g1, dim3(256), lds, st, a);
     launch_softmax_pool_t<DT, WV>(a, st);
 }

@@ -133,9 +133,9 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a)
     uint32_t* buf = reinterpret_cast<uint32_t*>(smem + (size_t)a.pow2 * 8);      // [2][SEL_WAVES] + spare
 
     const int tid = threadIdx.x;
-    const int n = a.n, k = a.k;
-    const int head = blockIdx.x;
-    const raw* s = reinterpret_cast<const raw*>(a.scores) + (int64_t)head * n;
+    const int head = blockIdx.x, item = blockIdx.y;
+    const int n = a.n, k = a.k.v[item];
+    const raw* s = reinterpret_cast<const raw*>(a.scores.p[item]) + (int64_t)head * n;
 
 #if defined(KVC_STAMPS)
     unsigned long long stamps_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a)
     KVC_SSTAMP(3);
 
     // ---- 3. order ----
-    int64_t* out = a.idx + (int64_t)head * k;
+    int64_t* out = reinterpret_cast<int64_t*>(const_cast<void*>(a.idx.p[item])) + (int64_t)head * k;
     if (k <= 256) {
         // rank sort spread over the whole workgroup: composites are unique, rank = number of smaller composites.
         // thread t: element e = t % E (E = pow2 >= k), comparison slice t / E; slice partials are summed in LDS.
@@ -261,11 +261,11 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a)
         const int64_t tail0 = (int64_t)(a.gk.q_len - a.gk.window) - k;
         const int hk = h / a.gk.group;
         gather_head_rows<SEL_THREADS>(list, k, tail0, per_tensor, lanes_per_row, esz,
-                         reinterpret_cast<const char*>(a.gk.src) + ((int64_t)b * a.gk.stride_b + (int64_t)hk * a.gk.stride_h) * esz,
-                         reinterpret_cast<char*>(a.gk.out) + (int64_t)head * cap * row_bytes, a.gk.stride_l);
+                         reinterpret_cast<const char*>(a.gk.src.p[item]) + ((int64_t)b * a.gk.stride_b + (int64_t)hk * a.gk.stride_h) * esz,
+                         reinterpret_cast<char*>(const_cast<void*>(a.gk.out.p[item])) + (int64_t)head * cap * row_bytes, a.gk.stride_l);
         gather_head_rows<SEL_THREADS>(list, k, tail0, per_tensor, lanes_per_row, esz,
-                         reinterpret_cast<const char*>(a.gv.src) + ((int64_t)b * a.gv.stride_b + (int64_t)hk * a.gv.stride_h) * esz,
-                         reinterpret_cast<char*>(a.gv.out) + (int64_t)head * cap * row_bytes, a.gv.stride_l);
+                         reinterpret_cast<const char*>(a.gv.src.p[item]) + ((int64_t)b * a.gv.stride_b + (int64_t)hk * a.gv.stride_h) * esz,
+                         reinterpret_cast<char*>(const_cast<void*>(a.gv.out.p[item])) + (int64_t)head * cap * row_bytes, a.gv.stride_l);
     }
 #if defined(KVC_STAMPS)
     __syncthreads();
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a)
 
 template <int DT, int EPT, int THR>
 static int launch_t(const SelectArgs& a, hipStream_t st) {
-    const size_t lds = select_lds_bytes(a.k);
+    const size_t lds = select_lds_bytes(a.k_max);
     static size_t lds_ok = 0;
     if (lds > 64 * 1024 && lds > lds_ok) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&select_kernel<DT, EPT, THR>),
@@ -284,7 +284,7 @@ static int launch_t(const SelectArgs& a, hipStream_t st) {
             return KVC_ERR_HIP;
         lds_ok = lds;
     }
-    hipLaunchKernelGGL((select_kernel<DT, EPT, THR>), dim3((unsigned)a.heads), dim3(THR), lds, st, a);
+    hipLaunchKernelGGL((select_kernel<DT, EPT, THR>), dim3((unsigned)a.heads, (unsigned)a.n_items), dim3(THR), lds, st, a);
     return 0;
 }
 

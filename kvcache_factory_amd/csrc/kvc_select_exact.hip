@@ -26,10 +26,10 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const SelectArgs a, u6
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* stack = reinterpret_cast<int*>(smem);                        // 3 * 96 ints
     u64* lds_arr = reinterpret_cast<u64*>(smem + 1152);
-    const int lane = threadIdx.x, head = blockIdx.x;
-    const int n = a.n, k = a.k;
-    const raw* s = reinterpret_cast<const raw*>(a.scores) + (int64_t)head * n;
-    int64_t* out = a.idx + (int64_t)head * k;
+    const int lane = threadIdx.x, head = blockIdx.x, item = blockIdx.y;
+    const int n = a.n, k = a.k.v[item];
+    const raw* s = reinterpret_cast<const raw*>(a.scores.p[item]) + (int64_t)head * n;
+    int64_t* out = reinterpret_cast<int64_t*>(const_cast<void*>(a.idx.p[item])) + (int64_t)head * k;
     const bool use_partial_sort = (int64_t)k * 64 <= (int64_t)n;
 
     if (use_partial_sort) {
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const SelectArgs a, u6
         __syncthreads();
         for (int t = lane; t < k; t += 64) out[t] = (int64_t)(lds_arr[t] & 0xffffffffull);
     } else {
-        u64* arr = arr_in_lds ? lds_arr : gscratch + (int64_t)head * n;
+        u64* arr = arr_in_lds ? lds_arr : gscratch + ((int64_t)item * a.heads + head) * n;
         for (int i = lane; i < n; i += 64) arr[i] = ((u64)Key<DT>::of(s[i]) << 32) | (uint32_t)i;
         __syncthreads();
         Arr A{arr};
@@ -78,9 +78,11 @@ size_t select_exact_scratch_bytes(int heads, int n, int k) {
 
 template <int DT>
 static int launch_exact_t(const SelectArgs& a, void* scratch, hipStream_t st) {
-    const bool partial = (int64_t)a.k * 64 <= (int64_t)a.n;
-    const int in_lds = partial || a.n <= 18000;
-    const size_t elems = partial ? (size_t)a.k : (in_lds ? (size_t)a.n : 0);
+    // LDS sized for the worst item: a heap of k_max (partial_sort regime) or the whole array (nth_element regime)
+    bool any_nth = false;
+    for (int i = 0; i < a.n_items; ++i) any_nth = any_nth || !((int64_t)a.k.v[i] * 64 <= (int64_t)a.n);
+    const int in_lds = !any_nth || a.n <= 18000;
+    const size_t elems = in_lds ? (any_nth ? (size_t)a.n : (size_t)a.k_max) : (size_t)a.k_max;
     const size_t lds = 1152 + elems * 8;
     if (!in_lds && !scratch) return KVC_ERR_WORKSPACE;
     static size_t lds_ok = 0;
@@ -90,7 +92,7 @@ static int launch_exact_t(const SelectArgs& a, void* scratch, hipStream_t st) {
             return KVC_ERR_HIP;
         lds_ok = lds;
     }
-    hipLaunchKernelGGL((select_exact_kernel<DT>), dim3((unsigned)a.heads), dim3(64), lds, st, a,
+    hipLaunchKernelGGL((select_exact_kernel<DT>), dim3((unsigned)a.heads, (unsigned)a.n_items), dim3(64), lds, st, a,
                        reinterpret_cast<u64*>(scratch), in_lds);
     return 0;
 }

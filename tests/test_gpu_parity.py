@@ -222,3 +222,18 @@ def test_fp16_conversion_matches_oracle(kvc, oracle, gpu_device):
     dev = x.to(gpu_device).to(torch.float16).cpu().view(torch.int16).to(torch.int32) & 0xFFFF
     L = oracle.lib()
     assert dev.tolist() == [L.kvco_f32_to_f16(float(t)) for t in x.tolist()]
+
+
+@pytest.mark.parametrize("tie", ["canonical", "torch_cpu"])
+def test_batched_layers_equal_per_layer_calls(kvc, gpu_device, tie):
+    """kvc_compress_batch (one launch of every kernel for all layers, per-layer PyramidKV budgets) gives byte-identical
+    K', V' and indices to one kvc_compress call per layer."""
+    L, W, cap, layers = 2048, 8, 96, 6
+    keeps = [kvc.pyramid_k(cap, W, L, l, layers) for l in range(layers)]
+    assert len(set(keeps)) > 1
+    qkv = [G.synth.make_qkv(32, 8, L, 128, torch.bfloat16, 50 + l, device=gpu_device) for l in range(layers)]
+    bp = kvc.BatchPlan(kvc.PYRAMIDKV, qkv, W, keeps, 7, "maxpool", tie, want_indices=True)
+    ko, vo = bp.run()
+    for l, (q, k, v) in enumerate(qkv):
+        k1, v1, i1 = kvc.compress(kvc.PYRAMIDKV, q, k, v, W, keeps[l], 7, "maxpool", tie, return_indices=True)
+        assert torch.equal(bp.idx[l], i1) and torch.equal(ko[l], k1) and torch.equal(vo[l], v1)
