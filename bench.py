@@ -197,6 +197,28 @@ def time_scan_kernel(plans, dev, reps=20):
     return e0.elapsed_time(e1) * 1e-3 / (reps * len(calls))
 
 
+def time_scan_kernel_batch(bstep, dev, reps=10):
+    """Same for the batched call: ONE logits_kernel launch covers all 32 layers (debug_stage_mask=1 on kvc_compress_batch)."""
+    lib, bp = _kvc.lib(), bstep.bp
+    pp = _kvc.Params.from_buffer_copy(bp.p)
+    pp.debug_stage_mask = 1
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def launch():
+        rc = lib.kvc_compress_batch(ctypes.byref(pp), bp.n, bp._keep, bp._q, bp._k, bp._v, bp._ko, bp._vo, bp._ix, None,
+                                    _kvc._ptr(bp.ws), bp.nbytes, stream)
+        assert rc == 0, lib.kvc_last_error()
+    launch()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
 def cpu_baseline(cfg, budget_s=12.0):
     """The CPU oracle (a port of the reference's algorithm, oracle/kvc_oracle.cpp) timed on this host's cores on a
     bounded sample of the same workload: whole layer calls of the bench config, repeated for ~budget_s seconds."""
@@ -310,12 +332,17 @@ def main():
     }
     if rank == 0:
         # ---- roofline of the dominant kernel (K scan), live HIP-event timing ----
-        t_scan = time_scan_kernel(call_plans, dev)
         es = 2
         scan_b, path_b = algorithmic_bytes(cfg["L"], cfg["W"], sum(ks) / len(ks), es)
+        if a.mode == "batch":
+            t_scan = time_scan_kernel_batch(plans[0], dev)        # one launch = 32 layers
+            scan_b *= LAYERS
+        else:
+            t_scan = time_scan_kernel(call_plans, dev)
         out["roofline"] = {"bound": "hbm", "kernel": "logits_kernel (K scan + window QK^T)", "achieved": scan_b / t_scan / 1e9,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": scan_b / t_scan / 1e9 / HBM_PEAK_GBS, "traffic": None,
                            "launch_us": t_scan * 1e6, "algorithmic_bytes_per_launch": scan_b,
+                           "units_per_launch": f"{cfg['L'] * (LAYERS if a.mode == 'batch' else 1)} tokens x 2056 B/token",
                            "path_achieved_GBs": path_b / (dt / a.steps / LAYERS) / 1e9,
                            "path_frac": path_b / (dt / a.steps / LAYERS) / 1e9 / HBM_PEAK_GBS,
                            "path_algorithmic_bytes_per_layer": path_b}
@@ -327,7 +354,7 @@ def main():
                     return [float(r["mean_per_dispatch"]) for r in csv.DictReader(fh)
                             if r["kernel"].startswith("kvc::logits_kernel") and r["counter"] == name][0]
             if a.config == "c2":
-                out["roofline"]["traffic"] = (2.0 * _pmc("FETCH_SIZE") + _pmc("WRITE_SIZE")) * 1024.0
+                out["roofline"]["traffic"] = (2.0 * _pmc("FETCH_SIZE") + _pmc("WRITE_SIZE")) * 1024.0 * (LAYERS if a.mode == "batch" else 1)
                 out["roofline"]["traffic_source"] = "profiles/r01_pmc_{FETCH,WRITE}_SIZE.csv (separate --pmc passes of the same kernel)"
         except Exception:
             pass

@@ -25,7 +25,7 @@ inline int esize_of(int dtype) { return dtype == KVC_FP32 ? 4 : 2; }
 inline bool scoring(int method) { return method == KVC_SNAPKV || method == KVC_PYRAMIDKV || method == KVC_H2O; }
 
 struct Layout {
-    size_t logits, ebuf, pmax, psum, rowmax, rowsum, scores, idx, exact, total;   // H2O: logits = S [L][L], rowmax/rowsum = [L] per head
+    size_t logits, pmax, psum, rowmax, rowsum, scores, idx, exact, total;   // H2O: logits = S [L][L], rowmax/rowsum = [L] per head
     int n_tiles, n_chunks;
 };
 
@@ -66,7 +66,7 @@ int check_strides(const char* what, int es, int64_t sb, int64_t sh, int64_t sl, 
     return KVC_OK;
 }
 
-Layout carve(const kvc_params* p) {
+Layout carve(const kvc_params* p, int n_items = 1) {
     Layout l;
     std::memset(&l, 0, sizeof(l));
     const size_t es = (size_t)esize_of(p->dtype);
@@ -78,6 +78,9 @@ Layout carve(const kvc_params* p) {
         int waves = 2048 / (kvh > 0 ? kvh : 1);
         if (waves < 4) waves = 4;
         if (waves > tiles32) waves = tiles32;
+        // a batch has parallelism to spare: give every wave ~4 tiles so the loads of tile t+1 overlap the MFMAs and the
+        // epilogue of tile t (double-buffered LDS) instead of relying on occupancy alone
+        if ((int64_t)n_items * kvh * tiles32 >= 8192) waves = (tiles32 + 3) / 4;
         l.n_tiles = (waves + 3) / 4;                       // workgroups per KV head == tile maxima per row
     }
     l.n_chunks = (int)((L + 255) / 256);
@@ -85,7 +88,6 @@ Layout carve(const kvc_params* p) {
     if (scoring(p->method)) {
         const size_t R = p->method == KVC_H2O ? L : W;     // query rows that score
         l.logits = off; off = align_up(off + heads * L * R * es, 256);
-        l.ebuf = off;   off = align_up(off + (p->method == KVC_H2O ? 0 : heads * L * W * 4), 256);
         l.pmax = off;   off = align_up(off + (p->method == KVC_H2O ? 0 : heads * (size_t)l.n_tiles * W * 4), 256);
         l.psum = off;   off = align_up(off + (p->method == KVC_H2O ? 0 : heads * (size_t)l.n_chunks * W * 4), 256);
         l.rowmax = off; off = align_up(off + heads * R * 4, 256);
@@ -148,7 +150,7 @@ int enqueue_scores(const kvc_params* p, const Layout& l, const Items& it, char* 
     for (int i = 0; i < it.n; ++i) { a.q.p[i] = it.q[i]; a.k.p[i] = it.k[i]; a.scores.p[i] = it.scores[i]; }
     a.n_items = it.n;
     a.ws = ws; a.ws_item_stride = (int64_t)l.total;
-    a.off_logits = (int64_t)l.logits; a.off_ebuf = (int64_t)l.ebuf; a.off_pmax = (int64_t)l.pmax;
+    a.off_logits = (int64_t)l.logits; a.off_pmax = (int64_t)l.pmax;
     a.off_psum = (int64_t)l.psum; a.off_rowmax = (int64_t)l.rowmax; a.off_rowsum = (int64_t)l.rowsum;
     a.q_stride_b = p->q_stride_b; a.q_stride_h = p->q_stride_h; a.q_stride_l = p->q_stride_l;
     a.k_stride_b = p->k_stride_b; a.k_stride_h = p->k_stride_h; a.k_stride_l = p->k_stride_l;
@@ -256,7 +258,7 @@ int run_items(const kvc_params* p, Items& it, void* workspace, size_t workspace_
     }
     kvc_params pk = *p;
     pk.k = it.k_max;
-    const Layout l = carve(&pk);
+    const Layout l = carve(&pk, it.n);
     const size_t exact = exact_scratch_total(p, it.n, it.keep);
     const size_t need = l.total * (size_t)it.n + exact;
     if (!workspace) return fail(KVC_ERR_WORKSPACE, "workspace is NULL, need %zu bytes", need);
@@ -277,6 +279,7 @@ int run_items(const kvc_params* p, Items& it, void* workspace, size_t workspace_
     if (int rc = check_strides("q", es, p->q_stride_b, p->q_stride_h, p->q_stride_l, it.q[0])) return rc;
     if (any_zero && it.n > 1) return fail(KVC_ERR_UNSUPPORTED, "a batch needs k >= 1 for every item");
     if (int rc = enqueue_scores(p, l, it, ws, st)) return rc;
+    if (p->debug_stage_mask != 0) return KVC_OK;            // profiling aid: only the selected scoring kernels
     if (it.k_max == 0) {                                     // nothing to select: only the window tail is kept
         const kvc::GatherArgs gk = gather_args(p, it, 0, false), gv = gather_args(p, it, 1, false);
         return enqueue_gather(&gk, &gv, st);
@@ -312,7 +315,7 @@ __attribute__((visibility("default"))) size_t kvc_workspace_bytes_batch(const kv
         if (k_per_item[i] > pk.k) pk.k = k_per_item[i];
     }
     g_err[0] = 0;
-    return carve(&pk).total * (size_t)n_items + exact_scratch_total(p, n_items, k_per_item);
+    return carve(&pk, n_items).total * (size_t)n_items + exact_scratch_total(p, n_items, k_per_item);
 }
 
 __attribute__((visibility("default"))) int kvc_workspace_layout(const kvc_params* p, size_t offs[3]) {
@@ -410,7 +413,6 @@ __attribute__((visibility("default"))) int kvc_compress_batch(const kvc_params* 
                                                               void* const* scores_out, void* workspace, size_t workspace_bytes,
                                                               void* hip_stream) {
     if (int rc = validate(p, true)) return rc;
-    if (p->debug_stage_mask != 0) return fail(KVC_ERR_INVALID, "debug_stage_mask is only honoured by kvc_scores");
     if (n_items < 1 || !k_per_item || !k || !v || !k_out || !v_out) return fail(KVC_ERR_INVALID, "n_items >= 1 and the pointer arrays must be non-NULL");
     if (scoring(p->method) && !q) return fail(KVC_ERR_INVALID, "q array must be non-NULL for scoring methods");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);

@@ -14,7 +14,7 @@ struct IntTable { int v[KVC_MAX_ITEMS]; };
 
 struct ScoreView {         // one item's pointers, resolved at kernel entry
     const void* q; const void* k;
-    void* logits; float* ebuf; float* pmax; float* psum; float* rowmax; float* rowsum; void* scores;
+    void* logits; float* pmax; float* psum; float* rowmax; float* rowsum; void* scores;
 };
 
 struct ScoreArgs {
@@ -23,7 +23,6 @@ struct ScoreArgs {
     int64_t ws_item_stride;
     // byte offsets inside an item's workspace:
     int64_t off_logits;    // [bsz*Hq][L][W] dtype
-    int64_t off_ebuf;      // [bsz*Hq][L][W] fp32: exp(logit - rowmax), written by rowsum_kernel, read by pool_kernel
     int64_t off_pmax;      // [bsz*Hq][n_tiles][W] fp32
     int64_t off_psum;      // [bsz*Hq][n_chunks][W] fp32
     int64_t off_rowmax;    // [bsz*Hq][W] fp32

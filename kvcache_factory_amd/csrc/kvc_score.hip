@@ -27,7 +27,6 @@ __device__ __forceinline__ ScoreView view_of(const ScoreArgs& a, int item) {
     ScoreView v;
     v.q = a.q.p[item]; v.k = a.k.p[item]; v.scores = const_cast<void*>(a.scores.p[item]);
     v.logits = w + a.off_logits;
-    v.ebuf = reinterpret_cast<float*>(w + a.off_ebuf);
     v.pmax = reinterpret_cast<float*>(w + a.off_pmax);
     v.psum = reinterpret_cast<float*>(w + a.off_psum);
     v.rowmax = reinterpret_cast<float*>(w + a.off_rowmax);
@@ -115,7 +114,7 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS: [Q image: 64 lanes x D/2 fp32, chunk-swizzled] [4 waves x nbuf x 32-key tile] [4 x 32 floats]
     char* const img = smem;
-    const int nbuf = a.nbuf;
+    constexpr int nbuf = 1;                  // one K-tile buffer per wave: the next tile is parked in registers
     char* const tiles = smem + 64 * IMGROW;
     float* wmax = reinterpret_cast<float*>(tiles + 4 * nbuf * 32 * ROWB);   // [4][32]
 
@@ -185,12 +184,11 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
         if (tile < n_t) commit(buf, st);
         KVC_STAMP(1);
         float runmax = -__builtin_inff();     // running maximum of this lane's row (see reduce-scatter below)
-        int cur = 0;
         for (; tile < n_t; tile += n_waves) {
             const int next = tile + n_waves;
             if (next < n_t) issue(next, st);                  // in flight during the MFMAs below
             __builtin_amdgcn_wave_barrier();
-            const char* krow = buf + cur * (32 * ROWB) + j * ROWB;
+            const char* krow = buf + j * ROWB;
             const char* arow = img + lane * IMGROW;
             const int key = tile * 32 + j;
             KVC_STAMP(2);
@@ -210,6 +208,9 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
                 }
             }
             asm volatile("" :: "v"(acc[0]), "v"(acc[15]));
+            // the tile's LDS reads are all issued (the LDS serves a wave in order): the next tile may overwrite the single
+            // buffer now, before the epilogue, so its ds_writes overlap the VALU work below
+            if (next < n_t) commit(buf, st);
             KVC_STAMP(3);
             // ---- epilogue: 3 roundings, mask, store [h][key][w] ----
             const bool tail = tile * 32 + 32 > L - W;          // wave-uniform: tile touches the masked W x W block
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void logits_kernel(const ScoreArgs a) {
                 runmax = m > runmax ? m : runmax;
             }
             KVC_STAMP(5);
-            if (next < n_t) { commit(buf + ((cur + 1) % nbuf) * (32 * ROWB), st); cur = (cur + 1) % nbuf; }
+
         }
         // ---- block-level maximum per row -> pmax[hq][blockIdx.x][w] ----
         {
@@ -373,21 +374,11 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const ScoreArgs a) {
     const int key = chunk * 256 + tid;
     float x[WV > 0 ? WV : 64];
     if (key < L) load_logits<DT, WV>(reinterpret_cast<const raw*>(vw.logits) + ((int64_t)hb * L + key) * W, W, x);
-    float* const erow = vw.ebuf + ((int64_t)hb * L + (key < L ? key : 0)) * W;       // e = exp(x - max), kept for pool_kernel
 #pragma unroll
     for (int w = 0; w < (WV > 0 ? WV : W); ++w) {
         float e = (key < L) ? exp_u20(x[w] - m[w]) : 0.0f;
-        x[w] = e;
         e = wave_xor_sum(e);
         if (lane == 0) wsum[wave * 64 + w] = e;
-    }
-    if (key < L) {
-        if constexpr (WV > 0) {
-#pragma unroll
-            for (int c = 0; c < WV / 4; ++c) reinterpret_cast<float4*>(erow)[c] = make_float4(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);
-        } else {
-            for (int w = 0; w < W; ++w) erow[w] = x[w];
-        }
     }
     __syncthreads();
     if (tid < W) {
@@ -438,20 +429,11 @@ __global__ __launch_bounds__(256) void pool_kernel(const ScoreArgs a) {
         float sv = 0.0f;
         if (key >= 0 && key < n) {
             float x[WV > 0 ? WV : 64];
-            const float* erow = vw.ebuf + ((int64_t)hb * L + key) * W;
-            if constexpr (WV > 0) {
-#pragma unroll
-                for (int c = 0; c < WV / 4; ++c) {
-                    const float4 v = reinterpret_cast<const float4*>(erow)[c];
-                    x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
-                }
-            } else {
-                for (int w = 0; w < W; ++w) x[w] = erow[w];
-            }
+            load_logits<DT, WV>(reinterpret_cast<const raw*>(vw.logits) + ((int64_t)hb * L + key) * W, W, x);
             CascadeSum cs;
             cs.init(W);
 #pragma unroll
-            for (int w = 0; w < (WV > 0 ? WV : W); ++w) cs.add(rnd<DT>(x[w] * rinv[w]));
+            for (int w = 0; w < (WV > 0 ? WV : W); ++w) cs.add(rnd<DT>(exp_u20(x[w] - m[w]) * rinv[w]));
             sv = rnd<DT>(cs.result());
         }
         s_tile[t] = sv;
@@ -495,7 +477,7 @@ static void launch_softmax_pool_t(const ScoreArgs& a, hipStream_t st) {
 template <int DT, int D, int WV>
 static void launch_all_t(const ScoreArgs& a, hipStream_t st) {
     constexpr int ES = Dt<DT>::esize;
-    const size_t lds = (size_t)64 * (D / 2) * 4 + (size_t)4 * a.nbuf * 32 * D * ES + 4 * 32 * sizeof(float);
+    const size_t lds = (size_t)64 * (D / 2) * 4 + (size_t)4 * 32 * D * ES + 4 * 32 * sizeof(float);
     static size_t lds_ok = 0;        // raise the dynamic-LDS limit once per instantiation, never inside the launch path again
     if (lds > 64 * 1024 && lds > lds_ok) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&logits_kernel<DT, D, WV>),

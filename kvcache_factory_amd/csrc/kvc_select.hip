@@ -33,7 +33,6 @@ namespace kvc {
 #endif
 
 static constexpr int SEL_MAX_WAVES = 16;           // workgroup size THR is a template parameter: 256, 512 or 1024 threads
-static constexpr int SEL_MAX_EPT = 256;         // n <= 65536 candidates per head
 
 size_t select_lds_bytes(int k) {
     int p = 1;

@@ -57,8 +57,12 @@ def test_workspace_bytes_and_layout(kvc):
     p = _p(kvc)
     n = L.kvc_workspace_bytes(ctypes.byref(p))
     # logits 32*8000*8*2 + tile maxima + chunk sums + scores + indices, each 256-B aligned
-    # logits 32*8000*8*2, exp buffer 32*8000*8*4, tile maxima, chunk sums, scores, indices — each 256-B aligned
-    assert n >= 32 * 8000 * 8 * 6 + 32 * 7992 * 2 + 32 * 120 * 8 and n < 16 * 1024 * 1024
+    # logits 32*8000*8*2, tile maxima, chunk sums, scores, indices — each 256-B aligned
+    assert n >= 32 * 8000 * 8 * 2 + 32 * 7992 * 2 + 32 * 120 * 8 and n < 8 * 1024 * 1024
+    keeps = (ctypes.c_int32 * 3)(120, 60, 17)
+    nb = L.kvc_workspace_bytes_batch(ctypes.byref(p), 3, keeps)
+    assert 3 * (32 * 8000 * 8 * 2) <= nb < 3 * n + 4096
+    assert L.kvc_workspace_bytes_batch(ctypes.byref(p), 0, keeps) == 0 and L.kvc_workspace_bytes_batch(ctypes.byref(p), 33, keeps) == 0
     offs = (ctypes.c_size_t * 3)()
     assert L.kvc_workspace_layout(ctypes.byref(p), ctypes.byref(offs)) == 0
     assert offs[0] == 0 and offs[1] % 256 == 0 and offs[2] > offs[1]
