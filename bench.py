@@ -39,8 +39,12 @@ CONFIGS = {
     "c5": dict(method="pyramidkv", L=32000, cap=2048, W=8, kernel=7, pooling="maxpool", dtype=torch.bfloat16,
                desc="PyramidKV Mistral-7B shapes, 32k -> 2048 (k_l = 3978..103)"),
 }
+CONFIGS["c3"] = dict(method="h2o", L=8000, cap=128, W=8, kernel=7, pooling=None, dtype=torch.bfloat16, layers=4,
+                     desc="H2O heavy-hitter scoring, Llama-3-8B shapes, seq_len=8000 -> 128, bf16 (all 8000 query rows score; "
+                          "4 layers per step: each layer materialises a 4.1 GB logit matrix)")
 HQ, HKV, D, LAYERS = 32, 8, 128, 32
-METHODS = {"snapkv": _kvc.SNAPKV, "pyramidkv": _kvc.PYRAMIDKV}
+MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md); the H2O kernel runs the exact f32-input MFMA (157 TF peak)
+METHODS = {"snapkv": _kvc.SNAPKV, "pyramidkv": _kvc.PYRAMIDKV, "h2o": _kvc.H2O}
 
 
 def algorithmic_bytes(L, W, k, es=2):
@@ -299,6 +303,11 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     cfg = CONFIGS[a.config]
+    global LAYERS
+    LAYERS = cfg.get("layers", LAYERS)
+    if cfg["method"] == "h2o":
+        a.mode, a.no_extras = "calls", True            # one 4.1 GB logit matrix at a time: sequential calls, one stream
+        a.streams = 1
 
     plans, ks = build_plans(cfg, dev, a.tie_mode, expanded=False, n_streams=a.streams, seed0=rank_seed(rank))
     run_step(plans)                      # first call outside any capture (one-time LDS attribute setup)
@@ -334,18 +343,29 @@ def main():
         # ---- roofline of the dominant kernel (K scan), live HIP-event timing ----
         es = 2
         scan_b, path_b = algorithmic_bytes(cfg["L"], cfg["W"], sum(ks) / len(ks), es)
-        if a.mode == "batch":
+        if cfg["method"] == "h2o":
+            t_scan = None
+        elif a.mode == "batch":
             t_scan = time_scan_kernel_batch(plans[0], dev)        # one launch = 32 layers
             scan_b *= LAYERS
         else:
             t_scan = time_scan_kernel(call_plans, dev)
-        out["roofline"] = {"bound": "hbm", "kernel": "logits_kernel (K scan + window QK^T)", "achieved": scan_b / t_scan / 1e9,
+        if cfg["method"] == "h2o":
+            # F = 2*Hq*L*L*D flop per layer (one QK^T); achieved over the whole per-layer time
+            flops = 2.0 * HQ * cfg["L"] * cfg["L"] * D
+            t_layer = dt / a.steps / LAYERS
+            out["roofline"] = {"bound": "mfma", "kernel": "h2o_logits_kernel (+ row/column softmax sums)", "achieved": flops / t_layer / 1e12,
+                               "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / t_layer / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
+                               "launch_us": t_layer * 1e6, "algorithmic_flops_per_layer": flops,
+                               "note": "exact-arithmetic version: f32-input MFMA (157 TF peak), logits materialised once"}
+            t_scan = 1.0
+        out.setdefault("roofline", {"bound": "hbm", "kernel": "logits_kernel (K scan + window QK^T)", "achieved": scan_b / t_scan / 1e9,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": scan_b / t_scan / 1e9 / HBM_PEAK_GBS, "traffic": None,
                            "launch_us": t_scan * 1e6, "algorithmic_bytes_per_launch": scan_b,
                            "units_per_launch": f"{cfg['L'] * (LAYERS if a.mode == 'batch' else 1)} tokens x 2056 B/token",
                            "path_achieved_GBs": path_b / (dt / a.steps / LAYERS) / 1e9,
                            "path_frac": path_b / (dt / a.steps / LAYERS) / 1e9 / HBM_PEAK_GBS,
-                           "path_algorithmic_bytes_per_layer": path_b}
+                           "path_algorithmic_bytes_per_layer": path_b})
         try:      # HBM bytes of the K-scan kernel from the committed PMC pass (profiles/, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE;
             #   gfx950 correction: FETCH_SIZE counts half of a wide coalesced read).  KB per dispatch -> bytes per launch.
             import csv

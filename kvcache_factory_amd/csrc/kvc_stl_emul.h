@@ -39,8 +39,12 @@ struct Arr {                 // random-access view of the (key<<32 | index) arra
     KVC_HD inline void swap(int i, int j) const { const u64 a = get(i), b = get(j); p[i] = b; p[j] = a; }
 };
 
+// (A register-resident variant of this view — heap slots on lanes, v_readlane/compare-select access — was measured
+// in round 1 and is SLOWER than LDS for a lone wave: the scalar program is issue-latency bound, not LDS bound.)
+
 // ---- libstdc++ bits/stl_heap.h ----------------------------------------------------------------------------
-KVC_HD inline void push_heap_(const Arr& A, int first, int hole, int top, u64 value) {
+template <class AT>
+KVC_HD inline void push_heap_(AT& A, int first, int hole, int top, u64 value) {
     int parent = (hole - 1) / 2;
     while (hole > top && comp(A.get(first + parent), value)) {
         A.set(first + hole, A.get(first + parent));
@@ -49,7 +53,8 @@ KVC_HD inline void push_heap_(const Arr& A, int first, int hole, int top, u64 va
     }
     A.set(first + hole, value);
 }
-KVC_HD inline void adjust_heap_(const Arr& A, int first, int hole, int len, u64 value) {
+template <class AT>
+KVC_HD inline void adjust_heap_(AT& A, int first, int hole, int len, u64 value) {
     const int top = hole;
     int second = hole;
     while (second < (len - 1) / 2) {
@@ -65,7 +70,8 @@ KVC_HD inline void adjust_heap_(const Arr& A, int first, int hole, int len, u64 
     }
     push_heap_(A, first, hole, top, value);
 }
-KVC_HD inline void make_heap_(const Arr& A, int first, int last) {
+template <class AT>
+KVC_HD inline void make_heap_(AT& A, int first, int last) {
     const int len = last - first;
     if (len < 2) return;
     int parent = (len - 2) / 2;
@@ -76,7 +82,8 @@ KVC_HD inline void make_heap_(const Arr& A, int first, int last) {
         parent--;
     }
 }
-KVC_HD inline void sort_heap_(const Arr& A, int first, int last) {
+template <class AT>
+KVC_HD inline void sort_heap_(AT& A, int first, int last) {
     while (last - first > 1) {
         --last;
         const u64 value = A.get(last);
@@ -85,7 +92,8 @@ KVC_HD inline void sort_heap_(const Arr& A, int first, int last) {
     }
 }
 // heap_select over an array that is fully materialised in A
-KVC_HD inline void heap_select_(const Arr& A, int first, int middle, int last) {
+template <class AT>
+KVC_HD inline void heap_select_(AT& A, int first, int middle, int last) {
     make_heap_(A, first, middle);
     for (int i = middle; i < last; ++i) {
         const u64 vi = A.get(i);
@@ -99,7 +107,8 @@ KVC_HD inline void heap_select_(const Arr& A, int first, int middle, int last) {
 // ---- libstdc++ bits/stl_algo.h ----------------------------------------------------------------------------
 KVC_HD inline int lg_(int n) { return 31 - __builtin_clz(n); }
 
-KVC_HD inline void move_median_to_first_(const Arr& A, int result, int a, int b, int c) {
+template <class AT>
+KVC_HD inline void move_median_to_first_(AT& A, int result, int a, int b, int c) {
     const u64 va = A.get(a), vb = A.get(b), vc = A.get(c);
     if (comp(va, vb)) {
         if (comp(vb, vc)) A.swap(result, b);
@@ -109,7 +118,8 @@ KVC_HD inline void move_median_to_first_(const Arr& A, int result, int a, int b,
     else if (comp(vb, vc)) A.swap(result, c);
     else A.swap(result, b);
 }
-KVC_HD inline int unguarded_partition_(const Arr& A, int first, int last, int pivot) {
+template <class AT>
+KVC_HD inline int unguarded_partition_(AT& A, int first, int last, int pivot) {
     const u64 pv = A.get(pivot);
     while (true) {
         while (comp(A.get(first), pv)) ++first;
@@ -120,12 +130,14 @@ KVC_HD inline int unguarded_partition_(const Arr& A, int first, int last, int pi
         ++first;
     }
 }
-KVC_HD inline int unguarded_partition_pivot_(const Arr& A, int first, int last) {
+template <class AT>
+KVC_HD inline int unguarded_partition_pivot_(AT& A, int first, int last) {
     const int mid = first + (last - first) / 2;
     move_median_to_first_(A, first, first + 1, mid, last - 1);
     return unguarded_partition_(A, first + 1, last, first);
 }
-KVC_HD inline void unguarded_linear_insert_(const Arr& A, int last) {
+template <class AT>
+KVC_HD inline void unguarded_linear_insert_(AT& A, int last) {
     const u64 val = A.get(last);
     int next = last - 1;
     while (comp(val, A.get(next))) {
@@ -135,7 +147,8 @@ KVC_HD inline void unguarded_linear_insert_(const Arr& A, int last) {
     }
     A.set(last, val);
 }
-KVC_HD inline void insertion_sort_(const Arr& A, int first, int last) {
+template <class AT>
+KVC_HD inline void insertion_sort_(AT& A, int first, int last) {
     if (first == last) return;
     for (int i = first + 1; i != last; ++i) {
         const u64 vi = A.get(i);
@@ -147,7 +160,8 @@ KVC_HD inline void insertion_sort_(const Arr& A, int first, int last) {
         }
     }
 }
-KVC_HD inline void introselect_(const Arr& A, int first, int nth, int last, int depth_limit) {
+template <class AT>
+KVC_HD inline void introselect_(AT& A, int first, int nth, int last, int depth_limit) {
     while (last - first > 3) {
         if (depth_limit == 0) {
             heap_select_(A, first, nth + 1, last);
@@ -161,7 +175,8 @@ KVC_HD inline void introselect_(const Arr& A, int first, int nth, int last, int 
     insertion_sort_(A, first, last);
 }
 // std::sort = introsort loop (explicit stack instead of recursion) + final insertion sort
-KVC_HD inline void sort_(const Arr& A, int first, int last, int* stack /*LDS, 3 ints per frame, >= 64 frames*/) {
+template <class AT>
+KVC_HD inline void sort_(AT& A, int first, int last, int* stack /*LDS, 3 ints per frame, >= 64 frames*/) {
     if (first == last) return;
     int sp = 0;
     int f = first, l = last, d = lg_(last - first) * 2;
