@@ -81,7 +81,7 @@ Layout carve(const kvc_params* p, int n_items = 1) {
         // a batch has parallelism to spare: give every wave ~4 tiles so the loads of tile t+1 overlap the MFMAs and the
         // epilogue of tile t (double-buffered LDS) instead of relying on occupancy alone
         if ((int64_t)n_items * kvh * tiles32 >= 8192) waves = (tiles32 + 3) / 4;
-        l.n_tiles = (waves + 3) / 4;                       // workgroups per KV head == tile maxima per row
+        l.n_tiles = (waves + 3) / 4;                       // workgroups (4 waves each) per KV head == tile maxima per row
     }
     l.n_chunks = (int)((L + 255) / 256);
     size_t off = 0;
@@ -160,7 +160,7 @@ int enqueue_scores(const kvc_params* p, const Layout& l, const Items& it, char* 
     a.n_tiles = l.n_tiles; a.n_chunks = l.n_chunks;
     a.kernel_size = p->kernel_size; a.pooling = p->pooling;
     a.stage_mask = p->debug_stage_mask;
-    a.nbuf = ((p->q_len + 31) / 32 + l.n_tiles * 4 - 1) / (l.n_tiles * 4) > 1 ? 2 : 1;
+    a.nbuf = 1;
     a.dbg = nullptr;
 #if defined(KVC_STAMPS)
     a.dbg = reinterpret_cast<unsigned long long*>(it.scores[0]);   // diagnostic build: stamps land in scores_out
