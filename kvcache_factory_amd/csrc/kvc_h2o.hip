@@ -181,11 +181,8 @@ template <int DT, int D>
 static int launch_h2o_t(const H2OArgs& a, hipStream_t st) {
     constexpr int ES = Dt<DT>::esize;
     const size_t lds = (size_t)4 * 2 * 32 * D * ES;
-    static size_t lds_ok = 0;
-    if (lds > 64 * 1024 && lds > lds_ok) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&h2o_logits_kernel<DT, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_ok = lds;
-    }
+    static LdsCache lds_cache = {};
+    if (ensure_lds(reinterpret_cast<const void*>(&h2o_logits_kernel<DT, D>), lds, lds_cache) != 0) return KVC_ERR_HIP;
     const int L = a.q_len, n = L - a.window, heads = a.bsz * a.n_q_heads;
     const int row_tiles = (L + 31) / 32;
     hipLaunchKernelGGL((h2o_logits_kernel<DT, D>), dim3((unsigned)((row_tiles + 3) / 4), (unsigned)heads), dim3(256), lds, st, a);

@@ -70,6 +70,20 @@ struct SelectArgs {
 
 struct GatherPair { GatherArgs t[2]; int count; };    // K and V compacted by one launch
 
+// Raise a kernel's dynamic-LDS limit above 64 KB once per (kernel instantiation, device): `cache` is a function-local
+// static array owned by the caller.  Never called again on the launch path, so launches stay graph-capturable.
+struct LdsCache { size_t ok[16]; };
+inline int ensure_lds(const void* func, size_t lds, LdsCache& cache) {
+    if (lds <= 64 * 1024) return 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 15;
+    if (lds <= cache.ok[dev]) return 0;
+    if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    cache.ok[dev] = lds;
+    return 0;
+}
+
 int launch_scores(const ScoreArgs& a, int dtype, int head_dim, hipStream_t st);
 int launch_h2o_scores(const H2OArgs& a, int dtype, int head_dim, hipStream_t st);
 int launch_select(const SelectArgs& a, int dtype, int tie_mode, hipStream_t st);

@@ -84,6 +84,7 @@ template <> __device__ __forceinline__ float pick<KVC_FP32>(const uint4& v, int 
 template <int D> struct ScaleDiv;            // x / sqrt(D) in fp32, bit-identical to the IEEE division
 template <> struct ScaleDiv<64> {            // sqrt(64) = 8: multiplying by 2^-3 IS the division (exact scaling)
     __device__ static __forceinline__ float apply(float x, float) { return x * 0.125f; }
+    __device__ static __forceinline__ float apply_in_guard(float x, float) { return x * 0.125f; }
 };
 template <> struct ScaleDiv<128> {
     // q0 = x*rc, r = fma(-q0, c, x), q = fma(r, rc, q0) equals RN(x / c) for c = sqrt(128) and EVERY finite fp32 x with
@@ -96,6 +97,13 @@ template <> struct ScaleDiv<128> {
         const float r = __builtin_fmaf(-q0, c, x);
         return __builtin_fmaf(r, rc, q0);
     }
+    // branch-free form for values already known to lie inside the guard (whole tile checked once: tile_in_guard)
+    __device__ static __forceinline__ float apply_in_guard(float x, float c) {
+        const float rc = u2f(0x3db504f3u);
+        const float q0 = x * rc;
+        const float r = __builtin_fmaf(-q0, c, x);
+        return __builtin_fmaf(r, rc, q0);
+    }
 };
 
 constexpr int LOGITS_WAVES = 4;              // waves per workgroup sharing one Q image: 48 KB LDS -> 3 groups per CU.
@@ -103,7 +111,7 @@ constexpr int LOGITS_WAVES = 4;              // waves per workgroup sharing one 
 constexpr int LOGITS_THREADS = LOGITS_WAVES * 64;
 
 template <int DT, int D, int WV>
-__global__ __launch_bounds__(LOGITS_THREADS) void logits_kernel(const ScoreArgs a) {
+__global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreArgs a) {
     const ScoreView vw = view_of(a, blockIdx.z);
     typedef typename Dt<DT>::raw raw;
     constexpr int ES = Dt<DT>::esize;
@@ -188,36 +196,67 @@ __global__ __launch_bounds__(LOGITS_THREADS) void logits_kernel(const ScoreArgs 
         if (tile < n_t) commit(buf, st);
         KVC_STAMP(1);
         float runmax = -__builtin_inff();     // running maximum of this lane's row (see reduce-scatter below)
-        for (; tile < n_t; tile += n_waves) {
-            const int next = tile + n_waves;
-            if (next < n_t) issue(next, st);                  // in flight during the MFMAs below
-            __builtin_amdgcn_wave_barrier();
-            const char* krow = buf + j * ROWB;
-            const char* arow = img + lane * IMGROW;
-            const int key = tile * 32 + j;
-            KVC_STAMP(2);
-            // ---- 32 rows x 32 keys, chain over d = 0..D-1 in order ----
-            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int ic = 0; ic < ICH; ++ic) {                 // one A chunk = 4 fragment values = 4 MFMAs
-                const float4 av = *reinterpret_cast<const float4*>(arow + ((ic ^ (lane & ISWZ)) * 16));
-                const float af[4] = {av.x, av.y, av.z, av.w};
-#pragma unroll
-                for (int kc = 0; kc < 4 / PAIRS; ++kc) {       // K chunks feeding these 4 values: 1 (16-bit) or 2 (fp32)
-                    const int c = ic * (4 / PAIRS) + kc;
-                    const uint4 kv = *reinterpret_cast<const uint4*>(krow + ((c ^ (j & SWZ)) * 16));
-#pragma unroll
-                    for (int s = 0; s < PAIRS; ++s)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc * PAIRS + s], pick<DT>(kv, s, psel), acc, 0, 0, 0);
-                }
+        const char* const krow = buf + j * ROWB;
+        const char* const arow = img + lane * IMGROW;
+
+        // One epilogue element: the reference's three roundings (+ the local causal mask on the last W keys).
+        auto finish = [&](float accv, int i, int key, bool tail) -> float {
+            float v = rnd<DT>(accv);
+            v = rnd<DT>(ScaleDiv<D>::apply(v, sqrt_d));
+            if (tail) {
+                const int w = i % W;
+                if (key >= L - W && (key - (L - W)) > w) v = rnd<DT>(v + Dt<DT>::finfo_min());
             }
-            asm volatile("" :: "v"(acc[0]), "v"(acc[15]));
-            // the tile's LDS reads are all issued (the LDS serves a wave in order): the next tile may overwrite the single
-            // buffer now, before the epilogue, so its ds_writes overlap the VALU work below
-            if (next < n_t) commit(buf, st);
-            KVC_STAMP(3);
-            // ---- epilogue: 3 roundings, mask, store [h][key][w] ----
-            const bool tail = tile * 32 + 32 > L - W;          // wave-uniform: tile touches the masked W x W block
+            return v;
+        };
+        auto finish_plain = [&](float accv) -> float {         // same three roundings, no mask, no branch
+            return rnd<DT>(ScaleDiv<D>::apply_in_guard(rnd<DT>(accv), sqrt_d));
+        };
+        // Store 4 consecutive rows (one accumulator register group) of one key: 8 bytes (16-bit) or 16 bytes (fp32).
+        auto store4 = [&](const float (&x)[4], int i0, int key) {
+            const int hq = g * G + i0 / W, w0 = i0 % W;
+            raw* dst = reinterpret_cast<raw*>(vw.logits) + (((int64_t)b * a.n_q_heads + hq) * L + key) * W + w0;
+            if constexpr (ES == 2) {
+                uint2 pk;
+                pk.x = (uint32_t)Dt<DT>::st(x[0]) | ((uint32_t)Dt<DT>::st(x[1]) << 16);
+                pk.y = (uint32_t)Dt<DT>::st(x[2]) | ((uint32_t)Dt<DT>::st(x[3]) << 16);
+                *reinterpret_cast<uint2*>(dst) = pk;
+            } else {
+                *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
+            }
+        };
+        // per-row maximum over a tile's 32 keys: reduce-scatter over the 5 key bits (16 cross-lane moves): after the
+        // step on lane bit t each lane keeps only the registers whose index bit matches its own.
+        auto fold_max = [&](const float (&xs)[16]) {
+            const bool b4 = (j & 16) != 0, b3 = (j & 8) != 0, b2 = (j & 4) != 0, b1 = (j & 2) != 0;
+            float y[8], z[4], u[2];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float o = xor_lane<16>(b4 ? xs[r] : xs[r + 8]);
+                const float keep = b4 ? xs[r + 8] : xs[r];
+                y[r] = o > keep ? o : keep;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float o = xor_lane<8>(b3 ? y[r] : y[r + 4]);
+                const float keep = b3 ? y[r + 4] : y[r];
+                z[r] = o > keep ? o : keep;
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float o = xor_lane<4>(b2 ? z[r] : z[r + 2]);
+                const float keep = b2 ? z[r + 2] : z[r];
+                u[r] = o > keep ? o : keep;
+            }
+            float m = xor_lane<2>(b1 ? u[0] : u[1]);
+            { const float keep = b1 ? u[1] : u[0]; m = m > keep ? m : keep; }
+            { const float o = xor_lane<1>(m); m = o > m ? o : m; }
+            runmax = m > runmax ? m : runmax;
+        };
+        // General epilogue (ragged tile, masked tail, padded rows, W % 4 != 0): straight after its own MFMAs.
+        auto epilogue_general = [&](const f32x16& acc, int t) {
+            const int key = t * 32 + j;
+            const bool tail = t * 32 + 32 > L - W;
             float xs[16];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
@@ -225,27 +264,12 @@ __global__ __launch_bounds__(LOGITS_THREADS) void logits_kernel(const ScoreArgs 
                 const int i0 = mt * 32 + 8 * rg + 4 * kh;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = rnd<DT>(acc[rg * 4 + e]);
-                    v = rnd<DT>(ScaleDiv<D>::apply(v, sqrt_d));
-                    if (tail) {
-                        const int w = (i0 + e) % W;
-                        if (key >= L - W && (key - (L - W)) > w) v = rnd<DT>(v + Dt<DT>::finfo_min());
-                    }
-                    x[e] = v;
-                    xs[rg * 4 + e] = (key < L) ? v : -__builtin_inff();
+                    x[e] = finish(acc[rg * 4 + e], i0 + e, key, tail);
+                    xs[rg * 4 + e] = (key < L) ? x[e] : -__builtin_inff();
                 }
                 if (i0 < rows && key < L) {
                     if ((W % 4) == 0) {
-                        const int hq = g * G + i0 / W, w0 = i0 % W;
-                        raw* dst = reinterpret_cast<raw*>(vw.logits) + (((int64_t)b * a.n_q_heads + hq) * L + key) * W + w0;
-                        if constexpr (ES == 2) {
-                            uint2 pk;
-                            pk.x = (uint32_t)Dt<DT>::st(x[0]) | ((uint32_t)Dt<DT>::st(x[1]) << 16);
-                            pk.y = (uint32_t)Dt<DT>::st(x[2]) | ((uint32_t)Dt<DT>::st(x[3]) << 16);
-                            *reinterpret_cast<uint2*>(dst) = pk;
-                        } else {
-                            *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
-                        }
+                        store4(x, i0, key);
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -258,37 +282,89 @@ __global__ __launch_bounds__(LOGITS_THREADS) void logits_kernel(const ScoreArgs 
                     }
                 }
             }
-            KVC_STAMP(4);
-            // per-row maximum over this tile's 32 keys: reduce-scatter over the 5 key bits (16 cross-lane moves):
-            // after the step on lane bit t each lane keeps only the registers whose index bit matches its own.
-            {
-                const bool b4 = (j & 16) != 0, b3 = (j & 8) != 0, b2 = (j & 4) != 0, b1 = (j & 2) != 0;
-                float y[8], z[4], u[2];
+            fold_max(xs);
+        };
+        // A tile is "plain" when none of those cases applies: its epilogue is then branch-free and is interleaved, one
+        // accumulator element per A chunk, with the MFMA chain of the NEXT tile (the chain alone leaves the wave
+        // stalled on its 64-cycle dependency for most of its issue slots: SQ_WAIT_INST_ANY was 56 % of wave cycles).
+        const bool rows_plain = (W % 4) == 0 && (mt + 1) * 32 <= rows;
+        constexpr int EPC = 16 / ICH;         // accumulator elements finished per A chunk
+        f32x16 pend = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int ptile = -1;                        // tile whose (plain) epilogue is still pending
+        for (; tile < n_t; tile += n_waves) {
+            const int next = tile + n_waves;
+            if (next < n_t) issue(next, st);                  // in flight during the MFMAs below
+            __builtin_amdgcn_wave_barrier();
+            KVC_STAMP(2);
+            // ---- 32 rows x 32 keys, chain over d = 0..D-1 in order ----
+            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (ptile >= 0) {
+                const int pkey = ptile * 32 + j;
+                float xs[16], x[4];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const float o = xor_lane<16>(b4 ? xs[r] : xs[r + 8]);
-                    const float keep = b4 ? xs[r + 8] : xs[r];
-                    y[r] = o > keep ? o : keep;
-                }
+                for (int ic = 0; ic < ICH; ++ic) {             // one A chunk = 4 fragment values = 4 MFMAs
+                    const float4 av = *reinterpret_cast<const float4*>(arow + ((ic ^ (lane & ISWZ)) * 16));
+                    const float af[4] = {av.x, av.y, av.z, av.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float o = xor_lane<8>(b3 ? y[r] : y[r + 4]);
-                    const float keep = b3 ? y[r + 4] : y[r];
-                    z[r] = o > keep ? o : keep;
-                }
+                    for (int kc = 0; kc < 4 / PAIRS; ++kc) {
+                        const int c = ic * (4 / PAIRS) + kc;
+                        const uint4 kv = *reinterpret_cast<const uint4*>(krow + ((c ^ (j & SWZ)) * 16));
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const float o = xor_lane<4>(b2 ? z[r] : z[r + 2]);
-                    const float keep = b2 ? z[r + 2] : z[r];
-                    u[r] = o > keep ? o : keep;
+                        for (int s = 0; s < PAIRS; ++s)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc * PAIRS + s], pick<DT>(kv, s, psel), acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < EPC; ++q) {            // previous tile's element e rides in this chain's shadow
+                        const int e = ic * EPC + q;
+                        const int i0 = mt * 32 + 8 * (e >> 2) + 4 * kh;
+                        const float v = finish_plain(pend[e]);
+                        x[e & 3] = v;
+                        xs[e] = v;
+                        if ((e & 3) == 3) store4(x, i0, pkey);
+                    }
+                    // ask the scheduler to lay this chunk out as MFMA, ~10 VALU, MFMA, ... instead of 4 back-to-back
+                    // dependent MFMAs followed by the element's VALU block
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                    }
                 }
-                float m = xor_lane<2>(b1 ? u[0] : u[1]);
-                { const float keep = b1 ? u[1] : u[0]; m = m > keep ? m : keep; }
-                { const float o = xor_lane<1>(m); m = o > m ? o : m; }
-                runmax = m > runmax ? m : runmax;
+                fold_max(xs);
+                ptile = -1;
+            } else {
+#pragma unroll
+                for (int ic = 0; ic < ICH; ++ic) {
+                    const float4 av = *reinterpret_cast<const float4*>(arow + ((ic ^ (lane & ISWZ)) * 16));
+                    const float af[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+                    for (int kc = 0; kc < 4 / PAIRS; ++kc) {
+                        const int c = ic * (4 / PAIRS) + kc;
+                        const uint4 kv = *reinterpret_cast<const uint4*>(krow + ((c ^ (j & SWZ)) * 16));
+#pragma unroll
+                        for (int s = 0; s < PAIRS; ++s)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc * PAIRS + s], pick<DT>(kv, s, psel), acc, 0, 0, 0);
+                    }
+                }
             }
+            asm volatile("" :: "v"(acc[0]), "v"(acc[15]));
+            // the tile's LDS reads are all issued (the LDS serves a wave in order): the next tile may overwrite the single
+            // buffer now, so its ds_writes overlap the VALU work that follows
+            if (next < n_t) commit(buf, st);
+            KVC_STAMP(3);
+            bool plain = rows_plain && tile * 32 + 32 <= L - W && next < n_t;
+            if (plain) {
+                // the branch-free scaling needs every |value| of the tile inside [2^-98, 2^126] (rounding to dtype moves a
+                // value by < 1 %, so this keeps the rounded value inside the proven [2^-100, inf) guard); a zero logit or
+                // an overflow sends the whole tile down the general path instead
+                float amin = __builtin_fabsf(acc[0]), amax = amin;
+#pragma unroll
+                for (int e = 1; e < 16; ++e) { const float t = __builtin_fabsf(acc[e]); amin = t < amin ? t : amin; amax = t > amax ? t : amax; }
+                plain = !__any(!(amin >= u2f(0x0e800000u) && amax <= u2f(0x7e800000u)));
+            }
+            if (plain) { pend = acc; ptile = tile; }           // finished under the next tile's MFMAs
+            else epilogue_general(acc, tile);
             KVC_STAMP(5);
-
         }
         // ---- block-level maximum per row -> pmax[hq][blockIdx.x][w] ----
         {
@@ -482,12 +558,8 @@ template <int DT, int D, int WV>
 static void launch_all_t(const ScoreArgs& a, hipStream_t st) {
     constexpr int ES = Dt<DT>::esize;
     const size_t lds = (size_t)64 * (D / 2) * 4 + (size_t)LOGITS_WAVES * 32 * D * ES + LOGITS_WAVES * 32 * sizeof(float);
-    static size_t lds_ok = 0;        // raise the dynamic-LDS limit once per instantiation, never inside the launch path again
-    if (lds > 64 * 1024 && lds > lds_ok) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&logits_kernel<DT, D, WV>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_ok = lds;
-    }
+    static LdsCache lds_cache = {};
+    (void)ensure_lds(reinterpret_cast<const void*>(&logits_kernel<DT, D, WV>), lds, lds_cache);   // a failure surfaces as a launch error
     dim3 g1((unsigned)a.n_tiles, (unsigned)(a.bsz * a.n_kv_heads), (unsigned)a.n_items);
     if ((a.stage_mask ? a.stage_mask : 7) & 1) hipLaunchKernelGGL((logits_kernel<DT, D, WV>), g1, dim3(LOGITS_THREADS), lds, st, a);
     launch_softmax_pool_t<DT, WV>(a, st);

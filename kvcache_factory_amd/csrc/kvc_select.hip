@@ -276,13 +276,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a)
 template <int DT, int EPT, int THR>
 static int launch_t(const SelectArgs& a, hipStream_t st) {
     const size_t lds = select_lds_bytes(a.k_max);
-    static size_t lds_ok = 0;
-    if (lds > 64 * 1024 && lds > lds_ok) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&select_kernel<DT, EPT, THR>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return KVC_ERR_HIP;
-        lds_ok = lds;
-    }
+    static LdsCache lds_cache = {};
+    if (ensure_lds(reinterpret_cast<const void*>(&select_kernel<DT, EPT, THR>), lds, lds_cache) != 0) return KVC_ERR_HIP;
     hipLaunchKernelGGL((select_kernel<DT, EPT, THR>), dim3((unsigned)a.heads, (unsigned)a.n_items), dim3(THR), lds, st, a);
     return 0;
 }

@@ -85,13 +85,8 @@ static int launch_exact_t(const SelectArgs& a, void* scratch, hipStream_t st) {
     const size_t elems = in_lds ? (any_nth ? (size_t)a.n : (size_t)a.k_max) : (size_t)a.k_max;
     const size_t lds = 1152 + elems * 8;
     if (!in_lds && !scratch) return KVC_ERR_WORKSPACE;
-    static size_t lds_ok = 0;
-    if (lds > 64 * 1024 && lds > lds_ok) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&select_exact_kernel<DT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return KVC_ERR_HIP;
-        lds_ok = lds;
-    }
+    static LdsCache lds_cache = {};
+    if (ensure_lds(reinterpret_cast<const void*>(&select_exact_kernel<DT>), lds, lds_cache) != 0) return KVC_ERR_HIP;
     hipLaunchKernelGGL((select_exact_kernel<DT>), dim3((unsigned)a.heads, (unsigned)a.n_items), dim3(64), lds, st, a,
                        reinterpret_cast<u64*>(scratch), in_lds);
     return 0;
