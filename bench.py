@@ -287,6 +287,8 @@ def main():
                          "calls: 32 kvc_compress calls per step spread over --streams streams")
     ap.add_argument("--streams", type=int, default=16, help="HIP streams the 32 independent layer calls are spread over")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kvc_compress call from the host instead of replaying a HIP graph of the step")
+    ap.add_argument("--dot-mode", default="exact", choices=["exact", "mfma16"],
+                    help="exact: f32-MFMA fmaf chain (bit-identical to the oracle); mfma16: packed bf16 MFMA scan (tolerance mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (expanded K/V, exact ties)")
     a = ap.parse_args()
@@ -303,6 +305,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     cfg = CONFIGS[a.config]
+    _kvc.DOT_MODE = a.dot_mode                 # default dot_mode of every plan built below
     global LAYERS
     LAYERS = cfg.get("layers", LAYERS)
     if cfg["method"] == "h2o":
@@ -336,7 +339,7 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": cfg["desc"], "name": a.config, "layers_per_step": LAYERS, "q_len": cfg["L"], "budget": cfg["cap"],
                    "kv_layout": "gqa_native [1,8,L,128] as the patched attention forward hands K/V over",
-                   "tie_mode": a.tie_mode, "mode": a.mode, "streams": a.streams if a.mode == "calls" else 1, "launch": launch_mode, "per_layer_us": dt / a.steps / LAYERS * 1e6,
+                   "tie_mode": a.tie_mode, "dot_mode": a.dot_mode, "mode": a.mode, "streams": a.streams if a.mode == "calls" else 1, "launch": launch_mode, "per_layer_us": dt / a.steps / LAYERS * 1e6,
                    "multi_gpu": "replicas, no collective"},
     }
     if rank == 0:
@@ -392,6 +395,17 @@ def main():
                 del p2
             except Exception as e:
                 extra[f"tie_mode_{other}_error"] = str(e)
+            if a.mode == "batch" and a.dot_mode == "exact":
+                try:
+                    _kvc.DOT_MODE = "mfma16"
+                    pf = [BatchStep(cfg, dev, a.tie_mode, call_plans, ks)]
+                    df = time_steps(pf, half, 1, dev, None)
+                    extra["tokens_per_s_dot_mode_mfma16_tolerance_mode"] = half * tokens_per_step / df
+                    del pf
+                except Exception as e:
+                    extra["dot_mode_mfma16_error"] = str(e)
+                finally:
+                    _kvc.DOT_MODE = a.dot_mode
             try:
                 d0 = time_steps(call_plans, half, 1, dev, None)
                 extra[f"tokens_per_s_32_kvc_compress_calls_{a.streams}_streams_host_enqueued"] = half * tokens_per_step / d0

@@ -58,6 +58,14 @@ typedef enum kvc_tie_mode {
     KVC_TIES_CANONICAL = 1     /* value descending, index ascending (fast path) */
 } kvc_tie_mode;
 
+typedef enum kvc_dot_mode {
+    KVC_DOT_EXACT = 0,         /* window QK^T as the d-ascending fp32 fmaf chain (f32-input MFMA): bit-identical to the CPU
+                                  oracle, and the arithmetic the reference's fp16/fp32 GEMM was measured to use */
+    KVC_DOT_MFMA16 = 1         /* packed bf16/fp16 16-deep MFMA (16x less matrix time; fp32 inputs fall back to EXACT).
+                                  Tolerance mode: a logit may differ from EXACT by 1 unit in the last place (~1e-4 of
+                                  the entries), which can move a candidate across the top-k threshold. */
+} kvc_dot_mode;
+
 typedef struct kvc_params {
     int32_t method;            /* kvc_method */
     int32_t dtype;             /* kvc_dtype of q, k, v and of every non-index output */
@@ -78,7 +86,7 @@ typedef struct kvc_params {
     int32_t debug_stage_mask;  /* profiling aid for kvc_scores / kvc_compress_batch: 0 = everything; else only the scoring
                                   kernels named by bit0 = K-scan (logits), bit1 = row-sum, bit2 = pool are enqueued.
                                   kvc_compress requires 0. */
-    int32_t reserved1;
+    int32_t dot_mode;          /* kvc_dot_mode (SnapKV / PyramidKV scan only; H2O is always EXACT) */
     int64_t q_stride_b, q_stride_h, q_stride_l;   /* element strides of q[b][h][l][:] */
     int64_t k_stride_b, k_stride_h, k_stride_l;
     int64_t v_stride_b, v_stride_h, v_stride_l;

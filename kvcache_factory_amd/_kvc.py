@@ -17,6 +17,9 @@ OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_ALIGNMENT, ERR_HIP = 0, -1,
 DTYPES = {torch.bfloat16: BF16, torch.float16: FP16, torch.float32: FP32}
 POOLINGS = {"avgpool": POOL_AVG, "maxpool": POOL_MAX, None: POOL_NONE, "none": POOL_NONE}
 TIE_MODES = {"torch_cpu": TIES_TORCH_CPU, "canonical": TIES_CANONICAL}
+DOT_EXACT, DOT_MFMA16 = 0, 1
+DOT_MODES = {"exact": DOT_EXACT, "mfma16": DOT_MFMA16}
+DOT_MODE = os.environ.get("KVC_DOT_MODE", "exact")      # default of every helper below
 
 EXPORTS = ("kvc_version", "kvc_last_error", "kvc_workspace_bytes", "kvc_compress", "kvc_scores", "kvc_select",
            "kvc_gather", "kvc_pyramid_k", "kvc_workspace_layout", "kvc_workspace_bytes_batch", "kvc_compress_batch")
@@ -31,7 +34,7 @@ class KvcError(RuntimeError):
 class Params(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "method", "dtype", "bsz", "n_q_heads", "n_kv_heads", "q_len", "head_dim", "window", "k",
-        "kernel_size", "pooling", "tie_mode", "debug_stage_mask", "reserved1")] + [
+        "kernel_size", "pooling", "tie_mode", "debug_stage_mask", "dot_mode")] + [
         (n, ctypes.c_int64) for n in (
             "q_stride_b", "q_stride_h", "q_stride_l", "k_stride_b", "k_stride_h", "k_stride_l",
             "v_stride_b", "v_stride_h", "v_stride_l")]
@@ -98,7 +101,7 @@ def _last_dim_contig(t):
     return t if t.stride(-1) == 1 else t.contiguous()
 
 
-def make_params(method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu"):
+def make_params(method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu", dot_mode=None):
     ref = k if k is not None else q
     p = Params()
     p.method = method
@@ -113,6 +116,8 @@ def make_params(method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool
         raise ValueError('Pooling method not supported')      # pyramidkv_utils.py:333
     p.pooling = POOLINGS[pooling]
     p.tie_mode = TIE_MODES[tie_mode] if isinstance(tie_mode, str) else tie_mode
+    dm = DOT_MODE if dot_mode is None else dot_mode
+    p.dot_mode = DOT_MODES[dm] if isinstance(dm, str) else dm
     if q is not None:
         p.q_stride_b, p.q_stride_h, p.q_stride_l = q.stride(0), q.stride(1), q.stride(2)
     if k is not None:
@@ -130,7 +135,7 @@ def _require_gpu(*ts):
 
 
 def compress(method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu",
-             n_q_heads=None, return_indices=False, return_scores=False):
+             n_q_heads=None, return_indices=False, return_scores=False, dot_mode=None):
     """One update_kv body on the GPU: returns (k_out, v_out[, idx][, scores])."""
     _require_gpu(q, k, v)
     k, v = _last_dim_contig(k), _last_dim_contig(v)
@@ -143,7 +148,7 @@ def compress(method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", 
         p.n_q_heads = hq
         qq = None
     else:
-        p = make_params(method, q, k, v, window, n_keep, kernel_size, pooling, tie_mode)
+        p = make_params(method, q, k, v, window, n_keep, kernel_size, pooling, tie_mode, dot_mode)
         hq, qq = q.shape[1], q
     bsz, L, D = k.shape[0], k.shape[2], k.shape[3]
     k_out = torch.empty(bsz, hq, n_keep + window, D, dtype=k.dtype, device=dev)
@@ -167,11 +172,11 @@ def compress(method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", 
     return tuple(out)
 
 
-def scores(method, q, k, window, kernel_size=5, pooling="avgpool", want_intermediates=False):
+def scores(method, q, k, window, kernel_size=5, pooling="avgpool", want_intermediates=False, dot_mode=None):
     """Stage A1-A5 only.  Returns pooled scores [bsz,Hq,L-W] (+ logits [bsz,Hq,L,W], rowmax, rowsum)."""
     _require_gpu(q, k)
     q, k = _last_dim_contig(q), _last_dim_contig(k)
-    p = make_params(method, q, k, None, window, 0, kernel_size, pooling)
+    p = make_params(method, q, k, None, window, 0, kernel_size, pooling, dot_mode=dot_mode)
     bsz, hq, L = q.shape[0], q.shape[1], q.shape[2]
     sc = torch.empty(bsz, hq, L - window, dtype=q.dtype, device=q.device)
     nbytes = lib().kvc_workspace_bytes(ctypes.byref(p))
@@ -234,14 +239,14 @@ class CompressPlan:
     same shapes, e.g. one plan per layer)."""
 
     def __init__(self, method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu",
-                 n_q_heads=None, want_indices=False, want_scores=False):
+                 n_q_heads=None, want_indices=False, want_scores=False, dot_mode=None):
         _require_gpu(q, k, v)
         self.q = _last_dim_contig(q) if q is not None else None
         self.k, self.v = _last_dim_contig(k), _last_dim_contig(v)
         dev = self.k.device
         scoring = method != STREAMINGLLM
         if scoring:
-            self.p = make_params(method, self.q, self.k, self.v, window, n_keep, kernel_size, pooling, tie_mode)
+            self.p = make_params(method, self.q, self.k, self.v, window, n_keep, kernel_size, pooling, tie_mode, dot_mode)
             hq = self.q.shape[1]
         else:
             hq = n_q_heads if n_q_heads is not None else self.k.shape[1]
@@ -273,7 +278,7 @@ class BatchPlan:
     budgets.  Everything is resolved once; run() is one C call that enqueues each kernel once for all items."""
 
     def __init__(self, method, qkv, window, n_keep, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu",
-                 want_indices=False):
+                 want_indices=False, dot_mode=None):
         n = len(qkv)
         q0, k0, v0 = qkv[0]
         _require_gpu(q0, k0, v0)
@@ -283,7 +288,7 @@ class BatchPlan:
                 k.stride() == self.items[0][1].stride() and v.stride() == self.items[0][2].stride(), "items must share one layout"
         keeps = list(n_keep) if hasattr(n_keep, "__len__") else [int(n_keep)] * n
         q, k, v = self.items[0]
-        self.p = make_params(method, q, k, v, window, max(keeps), kernel_size, pooling, tie_mode)
+        self.p = make_params(method, q, k, v, window, max(keeps), kernel_size, pooling, tie_mode, dot_mode)
         dev = k.device
         bsz, hq, D = k.shape[0], q.shape[1], k.shape[3]
         self.k_out = [torch.empty(bsz, hq, kk + window, D, dtype=k.dtype, device=dev) for kk in keeps]

@@ -44,6 +44,7 @@ int validate(const kvc_params* p, bool need_scores) {
     if (p->head_dim < 1 || (p->head_dim * es) % 16) return fail(KVC_ERR_UNSUPPORTED, "head_dim*esize must be a multiple of 16 bytes");
     if (p->head_dim * es > 4096) return fail(KVC_ERR_UNSUPPORTED, "head_dim too large");
     if (p->tie_mode != KVC_TIES_TORCH_CPU && p->tie_mode != KVC_TIES_CANONICAL) return fail(KVC_ERR_INVALID, "unknown tie_mode %d", p->tie_mode);
+    if (p->dot_mode != KVC_DOT_EXACT && p->dot_mode != KVC_DOT_MFMA16) return fail(KVC_ERR_INVALID, "unknown dot_mode %d", p->dot_mode);
     if (need_scores && scoring(p->method)) {
         if (p->head_dim != 64 && p->head_dim != 128) return fail(KVC_ERR_UNSUPPORTED, "scoring kernels are built for head_dim 64 and 128, got %d", p->head_dim);
         if (p->window > 64) return fail(KVC_ERR_UNSUPPORTED, "scoring window %d > 64 not built", p->window);
@@ -161,6 +162,7 @@ int enqueue_scores(const kvc_params* p, const Layout& l, const Items& it, char* 
     a.kernel_size = p->kernel_size; a.pooling = p->pooling;
     a.stage_mask = p->debug_stage_mask;
     a.nbuf = 1;
+    a.fast_dot = (p->dot_mode == KVC_DOT_MFMA16 && p->dtype != KVC_FP32) ? 1 : 0;
     a.dbg = nullptr;
 #if defined(KVC_STAMPS)
     a.dbg = reinterpret_cast<unsigned long long*>(it.scores[0]);   // diagnostic build: stamps land in scores_out

@@ -32,6 +32,7 @@ struct ScoreArgs {
     int64_t k_stride_b, k_stride_h, k_stride_l;
     int bsz, n_q_heads, n_kv_heads, group, q_len, window;
     int n_tiles, n_chunks, kernel_size, pooling;
+    int fast_dot;          // 1: packed bf16/fp16 MFMA scan (tolerance mode), 0: exact f32 fmaf-chain MFMA
     int nbuf;              // K-tile buffers per wave in logits_kernel: 1 if every wave owns a single tile, else 2
     int stage_mask;        // 0 = all; bit0 logits, bit1 rowsum, bit2 pool (profiling aid)
     float sqrt_d;

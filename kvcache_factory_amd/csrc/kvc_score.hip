@@ -110,7 +110,18 @@ constexpr int LOGITS_WAVES = 4;              // waves per workgroup sharing one 
                                              // (8 waves / 128 VGPRs / 4 waves per SIMD measured 12 % slower in batch mode, round 1.)
 constexpr int LOGITS_THREADS = LOGITS_WAVES * 64;
 
-template <int DT, int D, int WV>
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+// 16-deep MFMA step on packed bf16 / fp16 operands (FAST scan).  Its internal accumulation order is NOT the fmaf chain
+// (tools/mfma_probe.hip): logits may differ from the exact path by one unit in the last place on ~1e-4 of the entries.
+template <int DT> __device__ __forceinline__ f32x16 mfma16(const uint4& av, const uint4& bv, f32x16 acc) {
+    if constexpr (DT == KVC_BF16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, av), __builtin_bit_cast(s16x8, bv), acc, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, av), __builtin_bit_cast(h16x8, bv), acc, 0, 0, 0);
+}
+
+template <int DT, int D, int WV, bool FAST>
 __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreArgs a) {
     const ScoreView vw = view_of(a, blockIdx.z);
     typedef typename Dt<DT>::raw raw;
@@ -127,7 +138,9 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
     // LDS: [Q image: 64 lanes x D/2 fp32, chunk-swizzled] [LOGITS_WAVES x 32-key tile] [LOGITS_WAVES x 32 floats]
     char* const img = smem;
     constexpr int nbuf = 1;                  // one K-tile buffer per wave: the next tile is parked in registers
-    char* const tiles = smem + 64 * IMGROW;
+    constexpr int IMG_BYTES = FAST ? 0 : 64 * IMGROW;    // the FAST scan keeps its packed A fragments in registers
+    constexpr int NSTEP = FAST ? D / 16 : ICH;            // MFMA steps per tile: D/16 (packed 16-deep) or one per A chunk
+    char* const tiles = smem + IMG_BYTES;
     float* wmax = reinterpret_cast<float*>(tiles + LOGITS_WAVES * nbuf * 32 * ROWB);   // [waves][32]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
@@ -169,8 +182,19 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
         uint4 st[STG];
         int tile = wave_g;
         if (tile < n_t) issue(tile, st);
-        if (mt > 0) __syncthreads();                       // previous image no longer read
-        {
+        uint4 aq[FAST ? NSTEP : 1];                        // FAST: this lane's packed A fragments, chunk 2*s + kh of its row
+        if constexpr (FAST) {
+            const int i = mt * 32 + j;
+            const bool valid = i < rows;
+            const int hq = g * G + (valid ? i / W : 0), w = valid ? i % W : 0;
+            const char* qrow = reinterpret_cast<const char*>(vw.q) +
+                ((int64_t)b * a.q_stride_b + (int64_t)hq * a.q_stride_h + (int64_t)(L - W + w) * a.q_stride_l) * ES;
+#pragma unroll
+            for (int sI = 0; sI < NSTEP; ++sI)
+                aq[sI] = valid ? *reinterpret_cast<const uint4*>(qrow + (2 * sI + kh) * 16) : make_uint4(0, 0, 0, 0);
+        }
+        if (!FAST && mt > 0) __syncthreads();              // previous image no longer read
+        if constexpr (!FAST) {
             constexpr int PER_ROW = ROWB / 16;             // 16-byte pieces of one query row
             for (int pc = tid; pc < 32 * PER_ROW; pc += LOGITS_THREADS) {
                 const int r = pc / PER_ROW, cc = pc % PER_ROW;
@@ -192,7 +216,7 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
                 }
             }
         }
-        __syncthreads();
+        if (!FAST) __syncthreads();
         if (tile < n_t) commit(buf, st);
         KVC_STAMP(1);
         float runmax = -__builtin_inff();     // running maximum of this lane's row (see reduce-scatter below)
@@ -288,7 +312,25 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
         // accumulator element per A chunk, with the MFMA chain of the NEXT tile (the chain alone leaves the wave
         // stalled on its 64-cycle dependency for most of its issue slots: SQ_WAIT_INST_ANY was 56 % of wave cycles).
         const bool rows_plain = (W % 4) == 0 && (mt + 1) * 32 <= rows;
-        constexpr int EPC = 16 / ICH;         // accumulator elements finished per A chunk
+        constexpr int EPC = 16 / NSTEP;       // accumulator elements of the previous tile finished per MFMA step
+        // MFMA step sti of the current tile.
+        auto mfma_step = [&](int sti, f32x16& acc) {
+            if constexpr (FAST) {
+                const uint4 kv = *reinterpret_cast<const uint4*>(krow + (((2 * sti + kh) ^ (j & SWZ)) * 16));
+                acc = mfma16<DT>(aq[sti], kv, acc);
+            } else {                                           // one A chunk = 4 fragment values = 4 exact f32 MFMAs
+                const float4 av = *reinterpret_cast<const float4*>(arow + ((sti ^ (lane & ISWZ)) * 16));
+                const float af[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+                for (int kc = 0; kc < 4 / PAIRS; ++kc) {       // K chunks feeding these 4 values: 1 (16-bit) or 2 (fp32)
+                    const int c = sti * (4 / PAIRS) + kc;
+                    const uint4 kv = *reinterpret_cast<const uint4*>(krow + ((c ^ (j & SWZ)) * 16));
+#pragma unroll
+                    for (int s = 0; s < PAIRS; ++s)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc * PAIRS + s], pick<DT>(kv, s, psel), acc, 0, 0, 0);
+                }
+            }
+        };
         f32x16 pend = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         int ptile = -1;                        // tile whose (plain) epilogue is still pending
         for (; tile < n_t; tile += n_waves) {
@@ -302,17 +344,8 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
                 const int pkey = ptile * 32 + j;
                 float xs[16], x[4];
 #pragma unroll
-                for (int ic = 0; ic < ICH; ++ic) {             // one A chunk = 4 fragment values = 4 MFMAs
-                    const float4 av = *reinterpret_cast<const float4*>(arow + ((ic ^ (lane & ISWZ)) * 16));
-                    const float af[4] = {av.x, av.y, av.z, av.w};
-#pragma unroll
-                    for (int kc = 0; kc < 4 / PAIRS; ++kc) {
-                        const int c = ic * (4 / PAIRS) + kc;
-                        const uint4 kv = *reinterpret_cast<const uint4*>(krow + ((c ^ (j & SWZ)) * 16));
-#pragma unroll
-                        for (int s = 0; s < PAIRS; ++s)
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc * PAIRS + s], pick<DT>(kv, s, psel), acc, 0, 0, 0);
-                    }
+                for (int ic = 0; ic < NSTEP; ++ic) {
+                    mfma_step(ic, acc);
 #pragma unroll
                     for (int q = 0; q < EPC; ++q) {            // previous tile's element e rides in this chain's shadow
                         const int e = ic * EPC + q;
@@ -325,27 +358,16 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
                     // ask the scheduler to lay this chunk out as MFMA, ~10 VALU, MFMA, ... instead of 4 back-to-back
                     // dependent MFMAs followed by the element's VALU block
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < (FAST ? 1 : 4); ++q) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, FAST ? 40 : 10, 0);
                     }
                 }
                 fold_max(xs);
                 ptile = -1;
             } else {
 #pragma unroll
-                for (int ic = 0; ic < ICH; ++ic) {
-                    const float4 av = *reinterpret_cast<const float4*>(arow + ((ic ^ (lane & ISWZ)) * 16));
-                    const float af[4] = {av.x, av.y, av.z, av.w};
-#pragma unroll
-                    for (int kc = 0; kc < 4 / PAIRS; ++kc) {
-                        const int c = ic * (4 / PAIRS) + kc;
-                        const uint4 kv = *reinterpret_cast<const uint4*>(krow + ((c ^ (j & SWZ)) * 16));
-#pragma unroll
-                        for (int s = 0; s < PAIRS; ++s)
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc * PAIRS + s], pick<DT>(kv, s, psel), acc, 0, 0, 0);
-                    }
-                }
+                for (int ic = 0; ic < NSTEP; ++ic) mfma_step(ic, acc);
             }
             asm volatile("" :: "v"(acc[0]), "v"(acc[15]));
             // the tile's LDS reads are all issued (the LDS serves a wave in order): the next tile may overwrite the single
@@ -554,14 +576,26 @@ static void launch_softmax_pool_t(const ScoreArgs& a, hipStream_t st) {
     if (m & 4) hipLaunchKernelGGL((pool_kernel<DT, WV>), g3, dim3(256), 0, st, a);
 }
 
+template <int DT, int D, int WV, bool FAST>
+static void launch_logits_t(const ScoreArgs& a, hipStream_t st) {
+    constexpr int ES = Dt<DT>::esize;
+    const size_t lds = (FAST ? 0 : (size_t)64 * (D / 2) * 4) + (size_t)LOGITS_WAVES * 32 * D * ES + LOGITS_WAVES * 32 * sizeof(float);
+    static LdsCache lds_cache = {};
+    (void)ensure_lds(reinterpret_cast<const void*>(&logits_kernel<DT, D, WV, FAST>), lds, lds_cache);   // a failure surfaces as a launch error
+    dim3 g1((unsigned)a.n_tiles, (unsigned)(a.bsz * a.n_kv_heads), (unsigned)a.n_items);
+    hipLaunchKernelGGL((logits_kernel<DT, D, WV, FAST>), g1, dim3(LOGITS_THREADS), lds, st, a);
+}
+
 template <int DT, int D, int WV>
 static void launch_all_t(const ScoreArgs& a, hipStream_t st) {
-    constexpr int ES = Dt<DT>::esize;
-    const size_t lds = (size_t)64 * (D / 2) * 4 + (size_t)LOGITS_WAVES * 32 * D * ES + LOGITS_WAVES * 32 * sizeof(float);
-    static LdsCache lds_cache = {};
-    (void)ensure_lds(reinterpret_cast<const void*>(&logits_kernel<DT, D, WV>), lds, lds_cache);   // a failure surfaces as a launch error
-    dim3 g1((unsigned)a.n_tiles, (unsigned)(a.bsz * a.n_kv_heads), (unsigned)a.n_items);
-    if ((a.stage_mask ? a.stage_mask : 7) & 1) hipLaunchKernelGGL((logits_kernel<DT, D, WV>), g1, dim3(LOGITS_THREADS), lds, st, a);
+    if ((a.stage_mask ? a.stage_mask : 7) & 1) {
+        if constexpr (DT != KVC_FP32) {
+            if (a.fast_dot) launch_logits_t<DT, D, WV, true>(a, st);
+            else launch_logits_t<DT, D, WV, false>(a, st);
+        } else {
+            launch_logits_t<DT, D, WV, false>(a, st);
+        }
+    }
     launch_softmax_pool_t<DT, WV>(a, st);
 }
 

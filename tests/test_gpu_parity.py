@@ -237,3 +237,27 @@ def test_batched_layers_equal_per_layer_calls(kvc, gpu_device, tie):
     for l, (q, k, v) in enumerate(qkv):
         k1, v1, i1 = kvc.compress(kvc.PYRAMIDKV, q, k, v, W, keeps[l], 7, "maxpool", tie, return_indices=True)
         assert torch.equal(bp.idx[l], i1) and torch.equal(ko[l], k1) and torch.equal(vo[l], v1)
+
+
+@pytest.mark.parametrize("name", ["snap_bf16_maxpool_W8_L1024_D128", "snap_fp16_avgpool_W32_L1024_D128", "snap_bf16_maxpool_W8_L257_D64",
+                                  "C2_snapkv_8k_bf16", "C2_snapkv_8k_fp16", "C2_snapkv_8k_bf16_peaky", "C4_pyramidkv_8k_layer0"])
+def test_fast_dot_mode_within_tolerance(kvc, gpu_device, name):
+    """dot_mode = mfma16 (packed bf16/fp16 MFMA scan) is a TOLERANCE mode.  Stated tolerance: every logit equal to
+    the exact path within two units in the last place (rtol 2^-6 bf16 / 2^-9 fp16, atol 1e-4 for cancellation near zero) and
+    at most 0.1 % of them different; pooled scores likewise; with torch-CPU ties at least Hq-1 heads reproduce the reference's golden indices
+    (a flipped score can move one head's cut)."""
+    m, arr = G.MANIFEST[name], G.arrays(name)
+    qd, kd, vd = G.inputs(m, device=gpu_device, expanded=False)
+    sc_e, lg_e, _, _ = kvc.scores(kvc.SNAPKV, qd, kd, m["W"], m["kernel"], m["pooling"], want_intermediates=True, dot_mode="exact")
+    sc_f, lg_f, _, _ = kvc.scores(kvc.SNAPKV, qd, kd, m["W"], m["kernel"], m["pooling"], want_intermediates=True, dot_mode="mfma16")
+    rtol = 2.0 ** -6 if m["dtype"] == "bf16" else 2.0 ** -9           # two units in the last place of the dtype
+    for a, b in ((lg_e, lg_f), (sc_e, sc_f)):
+        a, b = a.cpu().float(), b.cpu().float()
+        finite = torch.isfinite(a) & torch.isfinite(b)
+        assert bool((torch.isfinite(a) == torch.isfinite(b)).all())
+        assert torch.allclose(a[finite], b[finite], rtol=rtol, atol=1e-4)   # atol: cancellation near zero logits
+        assert int((a != b).sum()) <= max(2, a.numel() // 1000)
+    ko, vo, idx = kvc.compress(METHOD[m["method"]], qd, kd, vd, m["W"], m["n_keep"], m["kernel"], m["pooling"], "torch_cpu",
+                               return_indices=True, dot_mode="mfma16")
+    ref_idx = torch.from_numpy(arr["indices"])
+    assert int((idx[0].cpu() == ref_idx).all(-1).sum()) >= m["Hq"] - 1
