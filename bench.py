@@ -373,12 +373,13 @@ def main():
             #   gfx950 correction: FETCH_SIZE counts half of a wide coalesced read).  KB per dispatch -> bytes per launch.
             import csv
             def _pmc(name):
-                with open(os.path.join(ROOT, "profiles", f"r01_pmc_{name}.csv")) as fh:
+                with open(os.path.join(ROOT, "profiles", f"r01_pmc_{'batch_' if a.mode == 'batch' else ''}{name}.csv")) as fh:
                     return [float(r["mean_per_dispatch"]) for r in csv.DictReader(fh)
                             if r["kernel"].startswith("kvc::logits_kernel") and r["counter"] == name][0]
             if a.config == "c2":
-                out["roofline"]["traffic"] = (2.0 * _pmc("FETCH_SIZE") + _pmc("WRITE_SIZE")) * 1024.0 * (LAYERS if a.mode == "batch" else 1)
-                out["roofline"]["traffic_source"] = "profiles/r01_pmc_{FETCH,WRITE}_SIZE.csv (separate --pmc passes of the same kernel)"
+                out["roofline"]["traffic"] = (2.0 * _pmc("FETCH_SIZE") + _pmc("WRITE_SIZE")) * 1024.0
+                out["roofline"]["traffic_source"] = ("profiles/r01_pmc_[batch_]{FETCH,WRITE}_SIZE.csv: separate rocprofv3 --pmc passes of the same "
+                                                     "launch; FETCH_SIZE doubled per the gfx950 correction; includes the logits the kernel writes")
         except Exception:
             pass
         if not a.no_extras and world == 1:

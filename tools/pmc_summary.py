@@ -14,8 +14,9 @@ for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=T
             key = (short, row["Counter_Name"])
             acc[key][0] += float(row["Counter_Value"])
             acc[key][1] += 1
-with open(out, "w") as fh:
-    fh.write("kernel,counter,mean_per_dispatch,dispatches\n")
+with open(out, "w", newline="") as fh:
+    w = csv.writer(fh, quoting=csv.QUOTE_NONNUMERIC)
+    w.writerow(["kernel", "counter", "mean_per_dispatch", "dispatches"])
     for (k, c), (s, n) in sorted(acc.items()):
-        fh.write(f"{k},{c},{s / n:.1f},{n}\n")
+        w.writerow([k, c, round(s / n, 1), n])
 print(open(out).read())
