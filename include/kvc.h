@@ -106,7 +106,9 @@ size_t kvc_workspace_bytes(const kvc_params* p);
  * tail (A8), for the method in p->method.  Replaces the body of
  *   SnapKVCluster.update_kv :317-346 / PyramidKVCluster.update_kv :220-283 /
  *   H2OKVCluster.update_kv :544-575 / StreamingLLMKVCluster.update_kv :607-620.
- * q: full query tensor base (row L-W.. are read; every row for H2O; ignored for StreamingLLM).
+ * q: query tensor base: row l of head h is read at q + b*q_stride_b + h*q_stride_h + l*q_stride_l.  SnapKV / PyramidKV
+ *    dereference rows L-W .. L-1 ONLY, so a caller that kept just the window rows ([b][h][W][D], as a layer-batching
+ *    host does) passes window_base - (L-W)*q_stride_l; H2O reads every row; StreamingLLM ignores q (may be NULL).
  * idx_out and scores_out may be NULL (scores_out is never written for StreamingLLM). */
 int kvc_compress(const kvc_params* p, const void* q, const void* k, const void* v,
                  void* k_out, void* v_out, int64_t* idx_out, void* scores_out,
@@ -114,8 +116,10 @@ int kvc_compress(const kvc_params* p, const void* q, const void* k, const void* 
 
 /* Batched form: n_items independent update_kv calls of IDENTICAL shape/dtype/strides (described by *p; p->k is
  * ignored) and per-item budgets k_per_item[i] — e.g. the 32 layers of one prompt (the reference runs them as 32
- * sequential calls, llama_model.py:285; they do not depend on each other).  Every kernel is launched once for up to
- * 32 items, so the small per-call kernels stop being launch-latency bound.  The arrays are HOST arrays of DEVICE
+ * sequential calls, llama_model.py:285; no call reads another's result, and the prefill attention of every layer runs
+ * on the UNcompressed K/V, llama_model.py:306-313, so a host may collect the layers and compress them after the last
+ * one).  Every kernel is launched once per chunk of 32 items (n_items may be larger; chunks reuse the workspace), so the
+ * small per-call kernels stop being launch-latency bound.  The arrays are HOST arrays of DEVICE
  * pointers (they are copied into the kernel arguments; nothing is staged on the device).  idx_out / scores_out may be
  * NULL, as may their entries.  Results are identical to n_items kvc_compress calls.
  * Workspace: kvc_workspace_bytes_batch(). */

@@ -275,37 +275,55 @@ class CompressPlan:
 
 class BatchPlan:
     """kvc_compress_batch over a list of (q, k, v) of identical shape — e.g. the layers of one prompt — with per-item
-    budgets.  Everything is resolved once; run() is one C call that enqueues each kernel once for all items."""
+    budgets.  Everything is resolved once; run() is one C call that enqueues each kernel once for all items.
+
+    q_rows="window": each q holds ONLY the scoring rows, [bsz, H_q, W, D] (the caller kept the last W query rows of a
+    layer instead of the whole projection).  The library addresses row l at q + l*q_stride_l and reads rows L-W..L-1
+    only (include/kvc.h), so the base handed over is window_base - (L-W)*q_stride_l.  Not for H2O (all rows score).
+    q may be None for StreamingLLM (n_q_heads then names the output heads)."""
 
     def __init__(self, method, qkv, window, n_keep, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu",
-                 want_indices=False, dot_mode=None):
+                 want_indices=False, dot_mode=None, q_rows="all", n_q_heads=None):
         n = len(qkv)
         q0, k0, v0 = qkv[0]
         _require_gpu(q0, k0, v0)
-        self.items = [(_last_dim_contig(q), _last_dim_contig(k), _last_dim_contig(v)) for q, k, v in qkv]
+        scoring = method != STREAMINGLLM
+        cq = (lambda t: _last_dim_contig(t)) if scoring else (lambda t: None)
+        self.items = [(cq(q), _last_dim_contig(k), _last_dim_contig(v)) for q, k, v in qkv]
+        i0 = self.items[0]
         for q, k, v in self.items:
-            assert q.shape == q0.shape and k.shape == k0.shape and q.stride() == self.items[0][0].stride() and \
-                k.stride() == self.items[0][1].stride() and v.stride() == self.items[0][2].stride(), "items must share one layout"
+            assert k.shape == i0[1].shape and k.stride() == i0[1].stride() and v.stride() == i0[2].stride() and \
+                k.dtype == i0[1].dtype and (not scoring or (q.shape == i0[0].shape and q.stride() == i0[0].stride())), \
+                "items must share one layout"
         keeps = list(n_keep) if hasattr(n_keep, "__len__") else [int(n_keep)] * n
-        q, k, v = self.items[0]
-        self.p = make_params(method, q, k, v, window, max(keeps), kernel_size, pooling, tie_mode, dot_mode)
+        q, k, v = i0
+        self.p = make_params(method, q, k, v, window, max(keeps), kernel_size, pooling if scoring else None, tie_mode,
+                             dot_mode)
+        if not scoring:
+            self.p.n_q_heads = n_q_heads if n_q_heads is not None else k.shape[1]
+        q_off = 0
+        if q_rows == "window":
+            assert scoring and method != H2O and q.shape[2] == window, "q_rows='window' needs [bsz,H,W,D] queries"
+            q_off = (k.shape[2] - window) * q.stride(2) * q.element_size()
+        else:
+            assert q_rows == "all" and (not scoring or q.shape[2] == k.shape[2])
         dev = k.device
-        bsz, hq, D = k.shape[0], q.shape[1], k.shape[3]
+        bsz, hq, D = k.shape[0], self.p.n_q_heads, k.shape[3]
         self.k_out = [torch.empty(bsz, hq, kk + window, D, dtype=k.dtype, device=dev) for kk in keeps]
         self.v_out = [torch.empty_like(t) for t in self.k_out]
-        self.idx = [torch.empty(bsz, hq, kk, dtype=torch.int64, device=dev) for kk in keeps] if want_indices else None
+        self.idx = [torch.empty(bsz, hq, kk, dtype=torch.int64, device=dev) for kk in keeps] if (want_indices and scoring) else None
         arr = ctypes.c_void_p * n
         self._keep = (ctypes.c_int32 * n)(*keeps)
-        self._q = arr(*[t[0].data_ptr() for t in self.items])
+        self._q = arr(*[t[0].data_ptr() - q_off for t in self.items]) if scoring else None
         self._k = arr(*[t[1].data_ptr() for t in self.items])
         self._v = arr(*[t[2].data_ptr() for t in self.items])
         self._ko = arr(*[t.data_ptr() for t in self.k_out])
         self._vo = arr(*[t.data_ptr() for t in self.v_out])
-        self._ix = arr(*[t.data_ptr() for t in self.idx]) if want_indices else None
+        self._ix = arr(*[t.data_ptr() for t in self.idx]) if self.idx is not None else None
         self.nbytes = lib().kvc_workspace_bytes_batch(ctypes.byref(self.p), n, self._keep)
-        if self.nbytes == 0:
+        if self.nbytes == 0 and scoring:
             raise KvcError(ERR_INVALID, lib().kvc_last_error().decode())
-        self.ws = workspace(dev, self.nbytes)
+        self.ws = workspace(dev, self.nbytes) if self.nbytes else None
         self.dev, self.n = dev, n
 
     def run(self, stream=None):
@@ -315,3 +333,14 @@ class BatchPlan:
         if rc:
             _check(rc)
         return self.k_out, self.v_out
+
+
+def compress_batch(method, qs, ks, vs, window, keeps, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu",
+                   q_rows="all", n_q_heads=None, return_indices=False, dot_mode=None):
+    """n independent update_kv bodies of one layout in ONE library call (kvc_compress_batch): lists of k_out, v_out
+    (and indices).  See BatchPlan for q_rows."""
+    qs = qs if qs is not None else [None] * len(ks)
+    bp = BatchPlan(method, list(zip(qs, ks, vs)), window, keeps, kernel_size, pooling, tie_mode, return_indices,
+                   dot_mode, q_rows, n_q_heads)
+    bp.run()
+    return (bp.k_out, bp.v_out, bp.idx) if return_indices else (bp.k_out, bp.v_out)

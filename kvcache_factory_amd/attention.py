@@ -6,6 +6,8 @@
     prefill  (this layer's cache is empty):                # reference: key_states.shape[-2] == kv_seq_len (:283)
         Kc, Vc = self.kv_cluster.update_kv(K, Q, V, attention_mask, num_key_value_groups)       (:285)
         cache <- Kc, Vc (H_q heads, cap tokens); true length remembered                         (:286,:290)
+        [default, pyramidkv_utils.BATCH_LAYERS: the call is parked in a PrefillBatch and the LAST layer runs all of
+         them as one kvc_compress_batch — same bytes, one launch of each kernel per prompt instead of one per layer]
         attention of THIS step runs over the uncompressed K, V                                  (:306-313)
     decode   : append the new token (expanded to H_q heads) and attend over cap + t tokens      (:287-289)
 
@@ -58,6 +60,14 @@ def _layer_for(cache, layer_idx):
     return layer
 
 
+def _pending_for(cache):
+    """The prompt's PrefillBatch, kept on the cache object (one per generation)."""
+    pending = getattr(cache, "_kvc_pending", None)
+    if pending is None:
+        pending = cache._kvc_pending = pu.PrefillBatch()
+    return pending
+
+
 def make_forward(method, apply_rotary_pos_emb, eager_attention_forward, repeat_kv, pass_sliding_window=False):
     init = _INIT[method]
 
@@ -74,14 +84,23 @@ def make_forward(method, apply_rotary_pos_emb, eager_attention_forward, repeat_k
         attn_module = self
         if past_key_values is not None:
             layer = _layer_for(past_key_values, self.layer_idx)
+            pending = _pending_for(past_key_values)
+            if pending.holds(layer):                                         # a prefill that never reached its last
+                pending.flush()                                              # layer: settle it before going on
             if layer.get_seq_length() == 0:                                  # prefill
                 q_len = key_states.shape[-2]
-                kc, vc = self.kv_cluster.update_kv(key_states, query_states, value_states, attention_mask,
-                                                   self.num_key_value_groups)
-                if kc is key_states:                                         # pass-through (q_len < cap): the
-                    kc = repeat_kv(key_states, self.num_key_value_groups)    # reference caches the expanded K/V
-                    vc = repeat_kv(value_states, self.num_key_value_groups)
-                layer.prefill(kc, vc, q_len)
+                taken = pu.BATCH_LAYERS and pending.add(
+                    self.kv_cluster, key_states, query_states, value_states,
+                    lambda kc, vc, layer=layer, q_len=q_len: layer.prefill(kc, vc, q_len), tag=layer)
+                if not taken:
+                    kc, vc = self.kv_cluster.update_kv(key_states, query_states, value_states, attention_mask,
+                                                       self.num_key_value_groups)
+                    if kc is key_states:                                     # pass-through (q_len < cap): the
+                        kc = repeat_kv(key_states, self.num_key_value_groups)    # reference caches the expanded K/V
+                        vc = repeat_kv(value_states, self.num_key_value_groups)
+                    layer.prefill(kc, vc, q_len)
+                if len(pending) and self.layer_idx == self.config.num_hidden_layers - 1:
+                    pending.flush()                                          # all layers of the prompt in ONE call
                 # this step's attention sees the full, uncompressed K/V (H_kv heads; the interface expands)
             else:                                                            # decode over the compressed cache
                 key_states = repeat_kv(key_states, self.num_key_value_groups)

@@ -309,15 +309,23 @@ __attribute__((visibility("default"))) size_t kvc_workspace_bytes(const kvc_para
 
 __attribute__((visibility("default"))) size_t kvc_workspace_bytes_batch(const kvc_params* p, int n_items, const int32_t* k_per_item) {
     if (validate(p, true) != KVC_OK) return 0;
-    if (n_items < 1 || n_items > kvc::KVC_MAX_ITEMS || !k_per_item) { fail(KVC_ERR_INVALID, "n_items must be in [1, %d]", kvc::KVC_MAX_ITEMS); return 0; }
-    kvc_params pk = *p;
-    pk.k = 0;
-    for (int i = 0; i < n_items; ++i) {
-        if (k_per_item[i] < 0 || k_per_item[i] > p->q_len - p->window) { fail(KVC_ERR_INVALID, "k=%d out of range (item %d)", k_per_item[i], i); return 0; }
-        if (k_per_item[i] > pk.k) pk.k = k_per_item[i];
+    if (n_items < 1 || !k_per_item) { fail(KVC_ERR_INVALID, "n_items must be >= 1 and k_per_item non-NULL"); return 0; }
+    // kvc_compress_batch runs chunks of KVC_MAX_ITEMS items one after the other in the same workspace: size the largest
+    size_t need = 0;
+    for (int base = 0; base < n_items; base += kvc::KVC_MAX_ITEMS) {
+        const int n = n_items - base < kvc::KVC_MAX_ITEMS ? n_items - base : kvc::KVC_MAX_ITEMS;
+        kvc_params pk = *p;
+        pk.k = 0;
+        for (int i = 0; i < n; ++i) {
+            const int kk = k_per_item[base + i];
+            if (kk < 0 || kk > p->q_len - p->window) { fail(KVC_ERR_INVALID, "k=%d out of range (item %d)", kk, base + i); return 0; }
+            if (kk > pk.k) pk.k = kk;
+        }
+        const size_t b = carve(&pk, n).total * (size_t)n + exact_scratch_total(p, n, k_per_item + base);
+        if (b > need) need = b;
     }
     g_err[0] = 0;
-    return carve(&pk, n_items).total * (size_t)n_items + exact_scratch_total(p, n_items, k_per_item);
+    return need;
 }
 
 __attribute__((visibility("default"))) int kvc_workspace_layout(const kvc_params* p, size_t offs[3]) {

@@ -11,6 +11,11 @@ by one call into the HIP library (include/kvc.h: kvc_compress).  Differences, al
     opt-in: set `kvcache_factory_amd.pyramidkv_utils.VERBOSE = True` (or KVC_VERBOSE=1).
   * `merge` (LOOK-M pivot merge, :119-170) is out of scope: anything but None raises.
   * tensors must live on the GPU: there is no CPU / eager fallback.
+  * `PrefillBatch` (not in the reference): the patched forwards hand every layer's (K, window-Q, V) to it and the
+    last layer flushes them through ONE kvc_compress_batch call.  Legal because the prefill attention of each layer
+    runs on the uncompressed K/V (llama_model.py:306-313) and nothing reads the compressed cache before the first
+    decode step; the bytes are those of per-layer update_kv calls.  `BATCH_LAYERS = False` (KVC_BATCH_LAYERS=0)
+    restores one update_kv per layer.
 """
 import math  # noqa: F401  (kept for parity with the reference's namespace)
 import os
@@ -21,6 +26,7 @@ from . import _kvc
 
 VERBOSE = os.environ.get("KVC_VERBOSE", "0") == "1"
 TIE_MODE = os.environ.get("KVC_TIE_MODE", "torch_cpu")   # "torch_cpu" (reference-exact ties) | "canonical"
+BATCH_LAYERS = os.environ.get("KVC_BATCH_LAYERS", "1") == "1"   # patched forwards compress all layers in one call
 
 
 def _say(msg):
@@ -80,6 +86,57 @@ class _KVCluster:
                                  n_q_heads=num_heads)
         return _run(self._method, key_states, query_states, value_states, self.window_size, n_keep,
                     self.kernel_size, self.pooling)
+
+
+class PrefillBatch:
+    """The update_kv calls of one prompt, collected layer by layer and run as one batched library call.
+
+    `add` does what update_kv does up to the compute (shape assert :309, budget, pass-through test :314, pooling /
+    merge errors :333/:164) and keeps K, V and a copy of the W scoring query rows; `flush` groups entries of one
+    layout, calls kvc_compress_batch per group and hands (key_states', value_states') to each entry's sink."""
+
+    def __init__(self):
+        self.entries = []
+
+    def __len__(self):
+        return len(self.entries)
+
+    def holds(self, tag):
+        return any(e[0] is tag for e in self.entries)
+
+    def add(self, cluster, key_states, query_states, value_states, sink, tag=None):
+        """True: taken (sink(kc, vc) runs at flush).  False: not batchable here (pass-through, H2O — whose scoring
+        needs every query row and is not launch-bound) — the caller runs cluster.update_kv itself."""
+        bsz, num_heads, q_len, head_dim = cluster._prefill_shapes(key_states, query_states)
+        if q_len < cluster.max_capacity_prompt or cluster._method == _kvc.H2O:
+            return False
+        n_keep = cluster._budget(q_len)
+        _say(f"{cluster._name} max_capacity_prompt {n_keep if cluster._method == _kvc.PYRAMIDKV else cluster.max_capacity_prompt}")
+        _check_merge(cluster.merge)
+        scoring = cluster._method != _kvc.STREAMINGLLM
+        if scoring and cluster.pooling not in ("avgpool", "maxpool"):
+            raise ValueError('Pooling method not supported')            # pyramidkv_utils.py:333
+        W = cluster.window_size
+        qw = query_states[:, :, q_len - W:, :].contiguous() if scoring else None
+        k, v = _kvc._last_dim_contig(key_states), _kvc._last_dim_contig(value_states)
+        layout = (cluster._method, tuple(k.shape), k.stride(), v.stride(), k.dtype, k.device, num_heads, W,
+                  cluster.kernel_size if scoring else 0, cluster.pooling if scoring else None)
+        self.entries.append((tag, layout, k, qw, v, n_keep, sink))
+        return True
+
+    def flush(self):
+        entries, self.entries = self.entries, []
+        groups = {}
+        for e in entries:
+            groups.setdefault(e[1], []).append(e)
+        for layout, es in groups.items():
+            method, _, _, _, _, _, num_heads, W, kernel_size, pooling = layout
+            scoring = method != _kvc.STREAMINGLLM
+            kc, vc = _kvc.compress_batch(method, [e[3] for e in es] if scoring else None, [e[2] for e in es],
+                                         [e[4] for e in es], W, [e[5] for e in es], kernel_size, pooling, TIE_MODE,
+                                         q_rows="window" if scoring else "all", n_q_heads=num_heads)
+            for e, a, b in zip(es, kc, vc):
+                e[6](a, b)
 
 
 class SnapKVCluster(_KVCluster):

@@ -25,3 +25,19 @@ def oracle_compress(method, q, k, v, window, n_keep, kernel_size=5, pooling="avg
     if return_scores:
         out.append(sc[None] if sc is not None else None)
     return tuple(out)
+
+
+def oracle_compress_batch(method, qs, ks, vs, window, keeps, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu",
+                          q_rows="all", n_q_heads=None, return_indices=False, dot_mode=None):
+    """Stand-in for _kvc.compress_batch: the items one after the other through oracle_compress."""
+    ko, vo, ix = [], [], []
+    for i, (k, v) in enumerate(zip(ks, vs)):
+        q = qs[i] if qs is not None else None
+        if q is not None and q_rows == "window":                     # rebuild a full-length q: only the last W rows score
+            assert q.shape[2] == window
+            full = torch.zeros(q.shape[0], q.shape[1], k.shape[2], q.shape[3], dtype=q.dtype)
+            full[:, :, -window:] = q
+            q = full
+        r = oracle_compress(method, q, k, v, window, keeps[i], kernel_size, pooling, tie_mode, n_q_heads, True)
+        ko.append(r[0]); vo.append(r[1]); ix.append(r[2])
+    return (ko, vo, ix) if return_indices else (ko, vo)

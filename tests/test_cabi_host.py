@@ -62,7 +62,9 @@ def test_workspace_bytes_and_layout(kvc):
     keeps = (ctypes.c_int32 * 3)(120, 60, 17)
     nb = L.kvc_workspace_bytes_batch(ctypes.byref(p), 3, keeps)
     assert 3 * (32 * 8000 * 8 * 2) <= nb < 3 * n + 4096
-    assert L.kvc_workspace_bytes_batch(ctypes.byref(p), 0, keeps) == 0 and L.kvc_workspace_bytes_batch(ctypes.byref(p), 33, keeps) == 0
+    assert L.kvc_workspace_bytes_batch(ctypes.byref(p), 0, keeps) == 0
+    many = (ctypes.c_int32 * 40)(*([120] * 40))          # > 32 items run as chunks in ONE workspace: sized for the largest chunk
+    assert L.kvc_workspace_bytes_batch(ctypes.byref(p), 40, many) == L.kvc_workspace_bytes_batch(ctypes.byref(p), 32, many)
     offs = (ctypes.c_size_t * 3)()
     assert L.kvc_workspace_layout(ctypes.byref(p), ctypes.byref(offs)) == 0
     assert offs[0] == 0 and offs[1] % 256 == 0 and offs[2] > offs[1]

@@ -261,3 +261,72 @@ def test_fast_dot_mode_within_tolerance(kvc, gpu_device, name):
                                return_indices=True, dot_mode="mfma16")
     ref_idx = torch.from_numpy(arr["indices"])
     assert int((idx[0].cpu() == ref_idx).all(-1).sum()) >= m["Hq"] - 1
+
+
+@pytest.mark.parametrize("method", ["snapkv", "pyramidkv", "streamingllm"])
+def test_compress_batch_window_queries_and_chunks(kvc, gpu_device, method):
+    """compress_batch as the layer-batching host uses it: only the W scoring query rows are kept per item
+    (q_rows="window": base = window_base - (L-W)*stride, include/kvc.h), 40 items (two chunks of <= 32 launches) —
+    byte-identical to one kvc_compress per item on the full-length q."""
+    L, W, cap, n = 640, 8, 72, 40
+    meth = METHOD[method]
+    keeps = [kvc.pyramid_k(cap, W, L, l, n) for l in range(n)] if method == "pyramidkv" else [cap - W] * n
+    qkv = [G.synth.make_qkv(32, 8, L, 128, torch.bfloat16, 300 + l, device=gpu_device) for l in range(n)]
+    scoring = method != "streamingllm"
+    qs = [q[:, :, L - W:].contiguous() for q, _, _ in qkv] if scoring else None
+    out = kvc.compress_batch(meth, qs, [k for _, k, _ in qkv], [v for _, _, v in qkv], W, keeps, 7, "maxpool", "torch_cpu",
+                             q_rows="window" if scoring else "all", n_q_heads=32, return_indices=scoring)
+    for l, (q, k, v) in enumerate(qkv):
+        r = kvc.compress(meth, q if scoring else None, k, v, W, keeps[l], 7, "maxpool", "torch_cpu", n_q_heads=32,
+                         return_indices=True)
+        assert torch.equal(out[0][l], r[0]) and torch.equal(out[1][l], r[1])
+        if scoring:
+            assert torch.equal(out[2][l], r[2])
+
+
+@pytest.mark.parametrize("method", ["snapkv", "pyramidkv", "h2o", "streamingllm"])
+def test_patched_model_on_gpu_layer_batching(kvc, gpu_device, method):
+    """replace_llama(method) on a small bf16 Llama (Llama-3 head geometry: 32 q / 8 kv heads of 128) ON THE GPU:
+    the prompt's layers compressed by one kvc_compress_batch (default) give the same cache bytes, true lengths and
+    generated tokens as one update_kv per layer; each layer's cache equals kvc.compress on the tensors the cluster saw."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from kvcache_factory_amd import monkeypatch as mp, pyramidkv_utils as pu
+    cfg = LlamaConfig(hidden_size=4096, intermediate_size=256, num_hidden_layers=4, num_attention_heads=32,
+                      num_key_value_heads=8, head_dim=128, vocab_size=256, max_position_embeddings=4096,
+                      attn_implementation="sdpa")
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(cfg).to(torch.bfloat16).to(gpu_device).eval()
+    L, cap, W = 700, 80, 8
+    ids = torch.randint(0, 256, (1, L), generator=torch.Generator().manual_seed(5)).to(gpu_device)
+    klass = {"snapkv": pu.SnapKVCluster, "pyramidkv": pu.PyramidKVCluster, "h2o": pu.H2OKVCluster,
+             "streamingllm": pu.StreamingLLMKVCluster}[method]
+    seen, orig, old_flag = [], klass.update_kv, pu.BATCH_LAYERS
+
+    def spy(self, k, q, v, am, g):
+        r = orig(self, k, q, v, am, g)
+        seen.append((self._budget(k.shape[-2]), k.clone(), q.clone(), v.clone()))
+        return r
+    outs = {}
+    try:
+        mp.replace_llama(method)
+        for layer in model.model.layers:
+            for name, val in (("window_size", W), ("max_capacity_prompt", cap), ("kernel_size", 7), ("pooling", "maxpool")):
+                setattr(layer.self_attn.config, name, val)
+        for flag in (True, False):
+            pu.BATCH_LAYERS = flag
+            klass.update_kv = spy if not flag else orig
+            with torch.no_grad():
+                outs[flag] = model.generate(ids, max_new_tokens=3, do_sample=False, use_cache=True, return_dict_in_generate=True)
+    finally:
+        klass.update_kv, pu.BATCH_LAYERS = orig, old_flag
+        mp.replace_llama("fullkv")
+    assert len(seen) == 4
+    assert torch.equal(outs[True].sequences, outs[False].sequences)
+    for li, (la, lb) in enumerate(zip(outs[True].past_key_values.layers, outs[False].past_key_values.layers)):
+        assert la.get_seq_length() == lb.get_seq_length() == L + 2
+        assert torch.equal(la.keys, lb.keys) and torch.equal(la.values, lb.values)
+        n_keep, k, q, v = seen[li]
+        ko, vo = kvc.compress(METHOD[method], q if method != "streamingllm" else None, k, v, W, n_keep, 7,
+                              "maxpool" if method != "h2o" else None, pu.TIE_MODE, n_q_heads=32)
+        assert la.keys.shape[2] == n_keep + W + 2 and torch.equal(la.keys[:, :, :n_keep + W], ko)
+        assert torch.equal(la.values[:, :, :n_keep + W], vo)

@@ -8,13 +8,15 @@ import pytest
 import torch
 
 import golden_util as G
-from cpu_compress import oracle_compress
+from cpu_compress import oracle_compress, oracle_compress_batch
 from kvcache_factory_amd import _kvc, monkeypatch as mp, pyramidkv_utils as pu
 
 
 @pytest.fixture()
 def cpu_backend(monkeypatch, oracle):
     monkeypatch.setattr(_kvc, "compress", oracle_compress)
+    monkeypatch.setattr(_kvc, "compress_batch", oracle_compress_batch)
+    monkeypatch.setattr(pu, "BATCH_LAYERS", False)       # these tests watch one update_kv per layer
     yield
 
 
@@ -188,3 +190,66 @@ def test_scored_methods_through_the_model(cpu_backend, method, cls):
         assert torch.equal(layer.keys[:, :, :n_keep + W], ko) and layer.get_seq_length() == L + 1
         assert layer.keys.shape[2] == n_keep + W + 1
     assert [int(p[0, 0]) for p in pos_seen] == [0, L]                   # prefill at 0.., decode at the TRUE length
+
+
+@pytest.mark.parametrize("method", ["snapkv", "pyramidkv", "streamingllm", "h2o"])
+def test_layer_batching_gives_the_per_layer_cache(cpu_backend, monkeypatch, method):
+    """pyramidkv_utils.BATCH_LAYERS: the patched forwards park every layer's update_kv in a PrefillBatch and the last
+    layer runs them as ONE compress_batch call (per-layer budgets for PyramidKV) — cache bytes, lengths and generated
+    tokens equal those of one update_kv per layer.  H2O is never parked (it scores with every query row)."""
+    model = _llama(3)
+    L, cap, W = 160, 48, 8
+    ids = torch.randint(0, 512, (1, L), generator=torch.Generator().manual_seed(3))
+    batch_calls = []
+
+    def spy_batch(method_, qs, ks, vs, window, keeps, *a, **kw):
+        batch_calls.append((len(ks), list(keeps), kw.get("q_rows"), None if qs is None else tuple(qs[0].shape)))
+        return oracle_compress_batch(method_, qs, ks, vs, window, keeps, *a, **kw)
+    monkeypatch.setattr(_kvc, "compress_batch", spy_batch)
+    outs = {}
+    try:
+        mp.replace_llama(method)
+        _set_knobs(model, window_size=W, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool")
+        for flag in (False, True):
+            monkeypatch.setattr(pu, "BATCH_LAYERS", flag)
+            outs[flag] = _generate(model, ids, 3)
+    finally:
+        mp.replace_llama("fullkv")
+    if method == "h2o":
+        assert batch_calls == []
+    else:
+        assert len(batch_calls) == 1 and batch_calls[0][0] == 3                 # one call, all three layers
+        if method == "pyramidkv":
+            assert len(set(batch_calls[0][1])) == 3                             # per-layer budgets travel with it
+        if method != "streamingllm":
+            assert batch_calls[0][2] == "window" and batch_calls[0][3] == (1, 32, W, 128)
+    assert torch.equal(outs[True].sequences, outs[False].sequences)
+    for la, lb in zip(outs[True].past_key_values.layers, outs[False].past_key_values.layers):
+        assert torch.equal(la.keys, lb.keys) and torch.equal(la.values, lb.values)
+        assert la.get_seq_length() == lb.get_seq_length() == L + 2
+    assert len(outs[True].past_key_values._kvc_pending) == 0
+
+
+def test_layer_batching_settles_an_unfinished_prefill(cpu_backend, monkeypatch):
+    """A prefill that stops before the last layer (only layer 0 is run here) leaves its entry parked; the next forward
+    of that layer flushes it first and then takes the decode branch at the true length."""
+    from transformers import DynamicCache
+    monkeypatch.setattr(pu, "BATCH_LAYERS", True)
+    model = _llama(2)
+    attn = model.model.layers[0].self_attn
+    try:
+        mp.replace_llama("snapkv")
+        _set_knobs(model, window_size=8, max_capacity_prompt=48, kernel_size=7, pooling="maxpool")
+        cache = DynamicCache()
+        g = torch.Generator().manual_seed(4)
+        hs = torch.randn(1, 100, 4096, generator=g)
+        pos = model.model.rotary_emb(hs, torch.arange(100)[None])
+        with torch.no_grad():
+            attn(hs, position_embeddings=pos, attention_mask=None, past_key_values=cache)
+            layer = cache.layers[0]
+            assert len(cache._kvc_pending) == 1 and layer.get_seq_length() == 0
+            pos1 = model.model.rotary_emb(hs[:, :1], torch.tensor([[100]]))
+            attn(hs[:, :1], position_embeddings=pos1, attention_mask=None, past_key_values=cache)
+        assert len(cache._kvc_pending) == 0 and layer.get_seq_length() == 101 and layer.keys.shape == (1, 32, 49, 128)
+    finally:
+        mp.replace_llama("fullkv")
