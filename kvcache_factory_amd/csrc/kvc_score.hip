@@ -15,6 +15,9 @@
 //                    e = exp_u20(x - max), fixed-order partial sums (oracle: sum_kvc).
 //   pool_kernel    : one workgroup = 256 candidate keys (+ pooling halo): p = round(e / sum),
 //                    window sum in torch's cascade order, round, pool, write the scores.
+#include <stdlib.h>
+#include <string.h>
+
 #include "kvc_common.h"
 #include "kvc_launch.h"
 
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row maxima of one head from the tile maxima: result in LDS m[0..W).  256 threads.
+// Row maxima of one head from the tile maxima: result in LDS m[0..W).  >= 256 threads (the first 256 work).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void block_row_max(const float* pmax /*[n_tiles][W]*/, int n_tiles, int W,
                                                float* m /*LDS [W]*/, float* scratch /*LDS [256]*/) {
@@ -418,9 +421,9 @@ __device__ __forceinline__ void block_row_max(const float* pmax /*[n_tiles][W]*/
     while (Wp < W) Wp <<= 1;               // W <= 64
     const int parts = 256 / Wp, w = tid % Wp, part = tid / Wp;
     float v = -__builtin_inff();
-    if (w < W)
+    if (w < W && tid < 256)
         for (int t = part; t < n_tiles; t += parts) { const float o = pmax[(int64_t)t * W + w]; v = o > v ? o : v; }
-    scratch[tid] = v;
+    if (tid < 256) scratch[tid] = v;
     __syncthreads();
     if (tid < W) {
         float r = scratch[tid];
@@ -564,11 +567,216 @@ __global__ __launch_bounds__(256) void pool_kernel(const ScoreArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// softmax_pool_kernel: rowsum_kernel + pool_kernel for one (head, item) in ONE workgroup of 1024 threads — the
+// same arithmetic in the same order (64-key butterflies, 4 per 256-key chunk left to right, chunks left to right),
+// so the bits are those of the two-kernel path.  Thread t owns keys t, t+1024, ...: a wave covers 64 consecutive
+// keys.  With KEEP > 0 the exponentials of the first pass stay in registers (KEEP iterations x WV rows) and are not
+// recomputed for the normalisation.  The per-key window sums go through a ring of four 1024-key segments in LDS so
+// that pooling reads its halo from the neighbouring segments (one barrier per iteration, nothing recomputed).
+// grid = (bsz*n_q_heads, items), block = 1024.  LDS: (iters*16 + n_chunks) * W floats + 16 KB + 1.5 KB.
+// ---------------------------------------------------------------------------------------------
+template <int WV> __device__ __forceinline__ int rs_row(int lane) {           // row a lane ends up holding
+    int row = 0, half = WV / 2;
+#pragma unroll
+    for (int s = 0; s < 6 && half >= 1; ++s, half >>= 1) row += ((lane >> s) & 1) * half;
+    return row;
+}
+// Butterfly sums over the wave for WV rows at once.  Steps with more than one row left exchange only the half of
+// the rows the partner keeps (both lanes of a pair compute the same a+b, so dropping one copy changes nothing);
+// result: the wave total of row rs_row<WV>(lane), bit-identical to wave_xor_sum() of that row.
+template <int WV, int MASK, int CNT> __device__ __forceinline__ void rs_step(float (&e)[WV], int lane) {
+    const bool bit = (lane & MASK) != 0;
+    if constexpr (CNT > 1) {
+        constexpr int H = CNT / 2;
+#pragma unroll
+        for (int r = 0; r < H; ++r) {
+            const float mine = bit ? e[r + H] : e[r], send = bit ? e[r] : e[r + H];
+            e[r] = mine + xor_lane<MASK>(send);
+        }
+    } else {
+        e[0] = e[0] + xor_lane<MASK>(e[0]);
+    }
+}
+template <int WV> __device__ __forceinline__ float wave_rows_sum(float (&e)[WV], int lane) {
+    rs_step<WV, 1, WV>(e, lane);
+    rs_step<WV, 2, (WV >= 2 ? WV / 2 : 1)>(e, lane);
+    rs_step<WV, 4, (WV >= 4 ? WV / 4 : 1)>(e, lane);
+    rs_step<WV, 8, (WV >= 8 ? WV / 8 : 1)>(e, lane);
+    rs_step<WV, 16, (WV >= 16 ? WV / 16 : 1)>(e, lane);
+    rs_step<WV, 32, (WV >= 32 ? WV / 32 : 1)>(e, lane);
+    return e[0];
+}
+
+constexpr int SP_THREADS = 1024;
+template <int DT, int WV, int KEEP>
+__global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArgs a) {
+    const ScoreView vw = view_of(a, blockIdx.y);
+    typedef typename Dt<DT>::raw raw;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int W = WV;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int hb = blockIdx.x;
+    const int L = a.q_len, n = L - W;
+    const int iters = (L + SP_THREADS - 1) / SP_THREADS;
+    float* const m = reinterpret_cast<float*>(smem);              // [64]
+    float* const rinv = m + 64;                                   // [64]
+    float* const scratch = rinv + 64;                             // [256]
+    float* const seg = scratch + 256;                             // [4][1024]
+    float* const wsum = seg + 4 * SP_THREADS;                     // [iters*16][W]
+    float* const csum = wsum + iters * 16 * W;                    // [n_chunks][W]
+    const raw* const lg = reinterpret_cast<const raw*>(vw.logits) + (int64_t)hb * L * W;
+
+    block_row_max(vw.pmax + (int64_t)hb * a.n_tiles * W, a.n_tiles, W, m, scratch);
+    float mr[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) mr[w] = m[w];
+
+    // pass 1: exponentials and their 64-key sums
+    float e[KEEP > 0 ? KEEP : 1][W];
+    const int my_row = rs_row<W>(lane);
+    if constexpr (KEEP > 0) {
+        float x[KEEP][W];
+#pragma unroll
+        for (int it = 0; it < KEEP; ++it) {
+            const int key = it * SP_THREADS + tid;
+            if (it < iters && key < L) load_logits<DT, W>(lg + (int64_t)key * W, W, x[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < KEEP; ++it) {
+            if (it < iters) {
+                const int key = it * SP_THREADS + tid;
+                float t[W];
+#pragma unroll
+                for (int w = 0; w < W; ++w) { e[it][w] = key < L ? exp_u20(x[it][w] - mr[w]) : 0.0f; t[w] = e[it][w]; }
+                const float tot = wave_rows_sum<W>(t, lane);
+                if (lane < W) wsum[(it * 16 + wave) * W + my_row] = tot;
+            }
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+            const int key = it * SP_THREADS + tid;
+            float x[W], t[W];
+            if (key < L) load_logits<DT, W>(lg + (int64_t)key * W, W, x);
+#pragma unroll
+            for (int w = 0; w < W; ++w) t[w] = key < L ? exp_u20(x[w] - mr[w]) : 0.0f;
+            const float tot = wave_rows_sum<W>(t, lane);
+            if (lane < W) wsum[(it * 16 + wave) * W + my_row] = tot;
+        }
+    }
+    __syncthreads();
+    // 256-key chunk sums (4 waves left to right), then the row totals (chunks left to right)
+    for (int t = tid; t < a.n_chunks * W; t += SP_THREADS) {
+        const int c = t / W, r = t - c * W;
+        const float* g = wsum + (int64_t)(4 * c) * W + r;
+        csum[t] = ((g[0] + g[W]) + g[2 * W]) + g[3 * W];
+    }
+    __syncthreads();
+    if (tid < W) {
+        float run = csum[tid];
+        for (int c = 1; c < a.n_chunks; ++c) run = run + csum[c * W + tid];
+        rinv[tid] = 1.0f / run;
+        vw.rowmax[(int64_t)hb * W + tid] = m[tid];
+        vw.rowsum[(int64_t)hb * W + tid] = run;
+    }
+    __syncthreads();
+    float ri[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) ri[w] = rinv[w];
+
+    // pass 2: p = round(e / sum), window sum (cascade), round; pooling one iteration behind through the segment ring
+    const int pad = a.pooling == KVC_POOL_NONE ? 0 : a.kernel_size / 2;
+    raw* const out = reinterpret_cast<raw*>(vw.scores) + (int64_t)hb * n;
+    auto pool_iteration = [&](int itp) {
+        const int jo = itp * SP_THREADS + tid;
+        if (jo >= n) return;
+        float c;
+        if (a.pooling == KVC_POOL_NONE) {
+            c = seg[(itp & 3) * SP_THREADS + tid];
+        } else {
+            const int lo = jo - pad < 0 ? 0 : jo - pad;
+            const int hi = jo - pad + a.kernel_size > n ? n : jo - pad + a.kernel_size;
+            if (a.pooling == KVC_POOL_MAX) {
+                c = -__builtin_inff();
+                for (int i = lo; i < hi; ++i) { const float v = seg[i & (4 * SP_THREADS - 1)]; c = v > c ? v : c; }
+            } else {
+                float acc = 0.0f;
+                for (int i = lo; i < hi; ++i) acc = acc + seg[i & (4 * SP_THREADS - 1)];
+                c = rnd<DT>(acc / (float)a.kernel_size);
+            }
+        }
+        out[jo] = Dt<DT>::st(c);
+    };
+    auto window_sum = [&](const float (&ev)[W]) {
+        CascadeSum cs;
+        cs.init(W);
+#pragma unroll
+        for (int w = 0; w < W; ++w) cs.add(rnd<DT>(ev[w] * ri[w]));
+        return rnd<DT>(cs.result());
+    };
+    if constexpr (KEEP > 0) {
+#pragma unroll
+        for (int it = 0; it <= KEEP; ++it) {
+            if (it <= iters) {
+                if (it < iters) {
+                    const int key = it * SP_THREADS + tid;
+                    seg[(it & 3) * SP_THREADS + tid] = key < n ? window_sum(e[it < KEEP ? it : 0]) : 0.0f;
+                }
+                __syncthreads();
+                if (it >= 1) pool_iteration(it - 1);
+            }
+        }
+    } else {
+        for (int it = 0; it <= iters; ++it) {
+            if (it < iters) {
+                const int key = it * SP_THREADS + tid;
+                float sv = 0.0f;
+                if (key < n) {
+                    float x[W], ev[W];
+                    load_logits<DT, W>(lg + (int64_t)key * W, W, x);
+#pragma unroll
+                    for (int w = 0; w < W; ++w) ev[w] = exp_u20(x[w] - mr[w]);
+                    sv = window_sum(ev);
+                }
+                seg[(it & 3) * SP_THREADS + tid] = sv;
+            }
+            __syncthreads();
+            if (it >= 1) pool_iteration(it - 1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host launch
 // ---------------------------------------------------------------------------------------------
+// One workgroup per head (softmax_pool_kernel) when there are enough heads x items to fill the chip (a prompt's layers
+// batched: -25 % on the two kernels' time); the two-kernel split (many workgroups per head) otherwise — with 32 heads
+// the fused form would occupy 32 of 256 CUs.  Same bits either way; KVC_SOFTMAX_PATH=split|fused
+// forces one for the parity tests.
+static int softmax_path_override() {
+    static const int v = [] {
+        const char* e = getenv("KVC_SOFTMAX_PATH");
+        return !e ? 0 : (!strcmp(e, "split") ? 1 : (!strcmp(e, "fused") ? 2 : 0));
+    }();
+    return v;
+}
 template <int DT, int WV>
 static void launch_softmax_pool_t(const ScoreArgs& a, hipStream_t st) {
     const int m = a.stage_mask ? a.stage_mask : 7;
+    if constexpr (WV > 0) {
+        const int iters = (a.q_len + SP_THREADS - 1) / SP_THREADS;
+        const size_t lds = (size_t)(64 + 64 + 256 + 4 * SP_THREADS + (iters * 16 + a.n_chunks) * WV) * sizeof(float);
+        const int heads = a.bsz * a.n_q_heads * a.n_items, ov = softmax_path_override();
+        const bool fits = lds <= 64 * 1024;
+        const bool fused = fits && ov != 1 && (ov == 2 || heads >= 128);
+        if (fused) {
+            if (!(m & 6)) return;
+            dim3 g((unsigned)(a.bsz * a.n_q_heads), (unsigned)a.n_items);
+            constexpr int KEEP = 64 / WV;                     // iterations whose exponentials stay in registers
+            if (KEEP >= 2 && iters <= KEEP) hipLaunchKernelGGL((softmax_pool_kernel<DT, WV, (KEEP >= 2 ? KEEP : 0)>), g, dim3(SP_THREADS), lds, st, a);
+            else hipLaunchKernelGGL((softmax_pool_kernel<DT, WV, 0>), g, dim3(SP_THREADS), lds, st, a);
+            return;
+        }
+    }
     dim3 g2((unsigned)a.n_chunks, (unsigned)(a.bsz * a.n_q_heads), (unsigned)a.n_items);
     if (m & 2) hipLaunchKernelGGL((rowsum_kernel<DT, WV>), g2, dim3(256), 0, st, a);
     const int n = a.q_len - a.window;

@@ -3,14 +3,18 @@
 //
 // torch-CPU topk (aten/native/cpu TopKImpl.h) sorts pair<value,index> with a value-only comparator using
 // libstdc++: std::partial_sort when k*64 <= n, otherwise std::nth_element(k-1) + std::sort(first k-1).  What those do
-// with equal values is a property of their exact sequence of moves, so this kernel EXECUTES that sequence:
-// one wavefront per head walks the same heap / introselect / introsort steps on order-preserving integer keys.
-// Every lane of the wave runs the same scalar program (values are made wave-uniform with readfirstlane), the
-// array lives in LDS when it fits (n <= 18000 elements of 8 bytes) and in the caller's workspace otherwise.
-// The partial_sort scan over the n-k tail is the only data-parallel part: 64 candidates are tested against the
-// heap root per step and only the ones that beat it are replayed serially.
+// with equal values is a property of their exact sequence of moves, so this kernel reproduces that sequence:
+// one wavefront per head.
 //
-// This is the slow, exact path (serial by construction); the canonical path is kvc_select.hip.
+//  * partial_sort with k <= 128 (the 8k -> 128 configurations): WaveHeap below.  The heap lives one or two nodes per
+//    lane; a whole __adjust_heap (sift the hole to the bottom, push the value back up) is ONE lane-parallel step —
+//    the sift-down path is known from a 64-bit mask of "which child wins" bits, so every node decides by itself
+//    whether it is on the path, the push-up stop is a ballot, and only the path's bits are refreshed afterwards.
+//    Same moves, same final array as the serial routine (kvc_stl_emul.h), ~4x fewer dependent steps.
+//  * everything else: the scalar program of kvc_stl_emul.h, every lane running the same code on wave-uniform values,
+//    array in LDS when it fits (n <= 18000 elements of 8 bytes) and in the caller's workspace otherwise.
+//
+// This is the exact path (serial by construction); the canonical path is kvc_select.hip.
 #include "kvc_common.h"
 #include "kvc_launch.h"
 #include "kvc_stl_emul.h"
@@ -18,7 +22,118 @@
 namespace kvc {
 
 // ---------------------------------------------------------------------------------------------------------
-// grid = heads, block = 64 (one wave).  LDS: array (or heap) + introsort stack.
+// WaveHeap: libstdc++'s binary heap (bits/stl_heap.h) of up to 128 (key<<32|index) elements held by one wavefront.
+// Node i lives on lane i (i < 64, `lo`) or lane i-64 (`hi`; for len <= 128 those are leaves).  arr[] (LDS) mirrors
+// the nodes so a lane can fetch its children; xl/xr cache them.  M bit p = 1  <=>  __adjust_heap at node p moves to
+// the LEFT child (comp(a[2p+2], a[2p+1]), or p has only a left child).
+// ---------------------------------------------------------------------------------------------------------
+struct WaveHeap {
+    u64 lo, hi;            // node values
+    u64 xl, xr;            // children of node `lane`
+    u64 A_lo, R_lo, A_hi, R_hi;   // ancestors of the node(s) and the M bits they must show for the node to be reached
+    u64 M;                 // wave-uniform
+    u64* arr;
+    int lane;
+
+    __device__ __forceinline__ static uint32_t key(u64 v) { return (uint32_t)(v >> 32); }
+    __device__ __forceinline__ static u64 rdlane(u64 v, int l) {
+        const uint32_t a = __builtin_amdgcn_readlane((uint32_t)v, l), b = __builtin_amdgcn_readlane((uint32_t)(v >> 32), l);
+        return ((u64)b << 32) | a;
+    }
+    __device__ __forceinline__ u64 node(int i) const { return i < 64 ? rdlane(lo, i) : rdlane(hi, i - 64); }
+
+    __device__ __forceinline__ void init(u64* lds, int len) {       // lo/hi set by the caller; arr[0..191] is ours
+        lane = threadIdx.x;
+        arr = lds;
+        A_lo = R_lo = A_hi = R_hi = 0;
+        for (int c = lane; c > 0;) { const int p = (c - 1) >> 1; A_lo |= 1ull << p; if (c & 1) R_lo |= 1ull << p; c = p; }
+        for (int c = lane + 64; c > 0;) { const int p = (c - 1) >> 1; A_hi |= 1ull << p; if (c & 1) R_hi |= 1ull << p; c = p; }
+        arr[lane] = lo; arr[lane + 64] = hi; arr[lane + 128] = 0;
+        __syncthreads();
+        xl = arr[2 * lane + 1]; xr = arr[2 * lane + 2];
+        M = __ballot(key(xr) > key(xl));
+        set_len(len);
+    }
+    __device__ __forceinline__ void set_len(int len) {               // a node with only a left child moves left
+        if (len >= 2 && (len & 1) == 0) M |= 1ull << ((len - 2) >> 1);
+    }
+    // __adjust_heap(first, t, len, value) + its __push_heap, all levels at once.  At = ancestors of t (0 for t = 0).
+    __device__ __forceinline__ void adjust(int t, u64 At, int len, u64 value) {
+        const bool on_lo = lane < len && (lane == t || (((A_lo >> t) & 1) && (((M ^ R_lo) & A_lo & ~At) == 0)));
+        const bool on_hi = lane + 64 < len && ((A_hi >> t) & 1) && (((M ^ R_hi) & A_hi & ~At) == 0);
+        const uint32_t vk = key(value);
+        // __push_heap climbs from the bottom of the path while comp(parent, value): it stops at the deepest path
+        // node (other than t) whose ORIGINAL value does not sort before `value`
+        const u64 c_lo = __ballot(on_lo && lane != t && !(key(lo) > vk));
+        const u64 c_hi = __ballot(on_hi && !(key(hi) > vk));
+        const int stop = c_hi ? 127 - __builtin_clzll(c_hi) : (c_lo ? 63 - __builtin_clzll(c_lo) : t);
+        const u64 child = ((M >> lane) & 1) ? xl : xr;                // the child the hole moved to
+        if (on_lo && lane <= stop) { lo = lane == stop ? value : child; arr[lane] = lo; }
+        if (on_hi && lane + 64 == stop) { hi = value; arr[lane + 64] = hi; }
+        __syncthreads();
+        // refresh the children (and the "which child" bit) of the path's nodes and of t's parent
+        const bool refresh = on_lo || (t > 0 && lane == ((t - 1) >> 1));
+        if (refresh) { xl = arr[2 * lane + 1]; xr = arr[2 * lane + 2]; }
+        const u64 P = __ballot(refresh), B = __ballot(refresh && key(xr) > key(xl));
+        M = (M & ~P) | B;
+        set_len(len);
+    }
+};
+
+// std::partial_sort(first, first + k, last, greater-by-value) for k <= 128, k >= 1; out[0..k) = indices.
+template <int DT>
+__device__ __forceinline__ void partial_sort_wave(const typename Dt<DT>::raw* s, int n, int k, u64* lds, int64_t* out) {
+    const int lane = threadIdx.x;
+    WaveHeap H;
+    H.lo = lane < k ? (((u64)Key<DT>::of(s[lane]) << 32) | (uint32_t)lane) : 0;
+    H.hi = lane + 64 < k ? (((u64)Key<DT>::of(s[lane + 64]) << 32) | (uint32_t)(lane + 64)) : 0;
+    H.init(lds, k);
+    // __make_heap
+    for (int t = (k - 2) / 2; t >= 0 && k >= 2; --t) H.adjust(t, WaveHeap::rdlane(H.A_lo, t), k, WaveHeap::rdlane(H.lo, t));
+    // __heap_select: every later element that sorts before the root replaces it (__pop_heap + __adjust_heap)
+    uint32_t root = WaveHeap::key(WaveHeap::rdlane(H.lo, 0));
+    constexpr int U = 8;
+    uint32_t cur[U], nxt[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) { const int i = k + j * 64 + lane; cur[j] = i < n ? Key<DT>::of(s[i]) : 0u; }
+    for (int base = k; base < n; base += U * 64) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) { const int i = base + (U + j) * 64 + lane; nxt[j] = i < n ? Key<DT>::of(s[i]) : 0u; }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int i0 = base + j * 64;
+            u64 pending = __ballot(i0 + lane < n && cur[j] > root);
+            while (pending) {
+                const int src = __builtin_ctzll(pending);
+                pending &= pending - 1;
+                const uint32_t kk = __builtin_amdgcn_readlane(cur[j], src);
+                if (kk > root) {                                       // re-test against the live root
+                    H.adjust(0, 0, k, ((u64)kk << 32) | (uint32_t)(i0 + src));
+                    root = WaveHeap::key(WaveHeap::rdlane(H.lo, 0));
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) cur[j] = nxt[j];
+    }
+    // __sort_heap: the root goes to a[last], a[last] is re-inserted from the top
+    u64* res = lds + 192;
+    for (int last = k - 1; last >= 1; --last) {
+        const u64 value = H.node(last), top = WaveHeap::rdlane(H.lo, 0);
+        if (lane == 0) res[last] = top;
+        H.set_len(last);
+        H.adjust(0, 0, last, value);
+    }
+    if (lane == 0) res[0] = H.lo;
+    __syncthreads();
+    for (int t = lane; t < k; t += 64) out[t] = (int64_t)(res[t] & 0xffffffffull);
+}
+
+constexpr int kWaveHeapMaxK = 128;
+constexpr size_t kWaveHeapLds = (192 + 128) * 8;
+
+// ---------------------------------------------------------------------------------------------------------
+// grid = (heads, items), block = 64 (one wave).  LDS: introsort stack + array (or heap).
 // ---------------------------------------------------------------------------------------------------------
 template <int DT>
 __global__ __launch_bounds__(64) void select_exact_kernel(const SelectArgs a, u64* gscratch /*[heads][n] or null*/, int arr_in_lds) {
@@ -32,7 +147,9 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const SelectArgs a, u6
     int64_t* out = reinterpret_cast<int64_t*>(const_cast<void*>(a.idx.p[item])) + (int64_t)head * k;
     const bool use_partial_sort = (int64_t)k * 64 <= (int64_t)n;
 
-    if (use_partial_sort) {
+    if (use_partial_sort && k <= kWaveHeapMaxK) {
+        partial_sort_wave<DT>(s, n, k, lds_arr, out);
+    } else if (use_partial_sort) {
         // heap of the first k in LDS; the tail is streamed 64 at a time
         Arr H{lds_arr};
         for (int i = lane; i < k; i += 64) lds_arr[i] = ((u64)Key<DT>::of(s[i]) << 32) | (uint32_t)i;
@@ -83,7 +200,7 @@ static int launch_exact_t(const SelectArgs& a, void* scratch, hipStream_t st) {
     for (int i = 0; i < a.n_items; ++i) any_nth = any_nth || !((int64_t)a.k.v[i] * 64 <= (int64_t)a.n);
     const int in_lds = !any_nth || a.n <= 18000;
     const size_t elems = in_lds ? (any_nth ? (size_t)a.n : (size_t)a.k_max) : (size_t)a.k_max;
-    const size_t lds = 1152 + elems * 8;
+    const size_t lds = 1152 + (elems * 8 > kWaveHeapLds ? elems * 8 : kWaveHeapLds);
     if (!in_lds && !scratch) return KVC_ERR_WORKSPACE;
     static LdsCache lds_cache = {};
     if (ensure_lds(reinterpret_cast<const void*>(&select_exact_kernel<DT>), lds, lds_cache) != 0) return KVC_ERR_HIP;
