@@ -83,9 +83,11 @@ typedef struct kvc_params {
     int32_t kernel_size;       /* pooling kernel (odd; padding = kernel_size/2, stride 1) (:328-333) */
     int32_t pooling;           /* kvc_pooling; ignored for H2O (no pooling, :555-561) and StreamingLLM */
     int32_t tie_mode;          /* kvc_tie_mode */
-    int32_t debug_stage_mask;  /* profiling aid for kvc_scores / kvc_compress_batch: 0 = everything; else only the scoring
-                                  kernels named by bit0 = K-scan (logits), bit1 = row-sum, bit2 = pool are enqueued.
-                                  kvc_compress requires 0. */
+    int32_t debug_stage_mask;  /* testing / profiling aid, 0 in production.  Bits 0-2 (kvc_scores, kvc_compress_batch): only the
+                                  scoring kernels named by bit0 = K-scan (logits), bit1 = row-sum, bit2 = pool are
+                                  enqueued; kvc_compress requires them 0.  Bit3 / bit4: force the two-kernel / the
+                                  one-workgroup-per-head form of the softmax+pool stage (identical results; the
+                                  library picks by the number of heads x items otherwise). */
     int32_t dot_mode;          /* kvc_dot_mode (SnapKV / PyramidKV scan only; H2O is always EXACT) */
     int64_t q_stride_b, q_stride_h, q_stride_l;   /* element strides of q[b][h][l][:] */
     int64_t k_stride_b, k_stride_h, k_stride_l;

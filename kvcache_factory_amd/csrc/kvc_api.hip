@@ -281,7 +281,7 @@ int run_items(const kvc_params* p, Items& it, void* workspace, size_t workspace_
     if (int rc = check_strides("q", es, p->q_stride_b, p->q_stride_h, p->q_stride_l, it.q[0])) return rc;
     if (any_zero && it.n > 1) return fail(KVC_ERR_UNSUPPORTED, "a batch needs k >= 1 for every item");
     if (int rc = enqueue_scores(p, l, it, ws, st)) return rc;
-    if (p->debug_stage_mask != 0) return KVC_OK;            // profiling aid: only the selected scoring kernels
+    if ((p->debug_stage_mask & 7) != 0) return KVC_OK;      // profiling aid: only the selected scoring kernels
     if (it.k_max == 0) {                                     // nothing to select: only the window tail is kept
         const kvc::GatherArgs gk = gather_args(p, it, 0, false), gv = gather_args(p, it, 1, false);
         return enqueue_gather(&gk, &gv, st);
@@ -408,7 +408,7 @@ __attribute__((visibility("default"))) int kvc_compress(const kvc_params* p, con
                                                         void* k_out, void* v_out, int64_t* idx_out, void* scores_out,
                                                         void* workspace, size_t workspace_bytes, void* hip_stream) {
     if (int rc = validate(p, true)) return rc;
-    if (p->debug_stage_mask != 0) return fail(KVC_ERR_INVALID, "debug_stage_mask is only honoured by kvc_scores");
+    if ((p->debug_stage_mask & 7) != 0) return fail(KVC_ERR_INVALID, "debug_stage_mask bits 0-2 are only honoured by kvc_scores / kvc_compress_batch");
     Items it;
     std::memset(&it, 0, sizeof(it));
     it.n = 1;

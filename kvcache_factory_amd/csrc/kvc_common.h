@@ -83,6 +83,34 @@ __device__ __forceinline__ float exp_u20(float x) {
     return p;
 }
 
+// Two exponentials at once: the same operations on the packed-fp32 ALU (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 are
+// per-element IEEE operations, so each half is bit-identical to exp_u20 of that half).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 exp_u20x2(f32x2 x) {
+    const float ln_flt_min = u2f(0xc2aeac50u), ln_flt_max = u2f(0x42b17218u);
+    const f32x2 log2ef = u2f(0x3fb8aa3bu), nln2f = -u2f(0x3f317218u);
+    const f32x2 c1 = 0.999999701f, c2 = 0.499991506f, c3 = 0.166676521f, c4 = 0.0418978221f, c5 = 0.00828929059f;
+    const bool below0 = x.x < ln_flt_min, below1 = x.y < ln_flt_min;
+    f32x2 s;
+    s.x = (x.x < ln_flt_max) ? x.x : ln_flt_max; s.x = (s.x > ln_flt_min) ? s.x : ln_flt_min;
+    s.y = (x.y < ln_flt_max) ? x.y : ln_flt_max; s.y = (s.y > ln_flt_min) ? s.y : ln_flt_min;
+    f32x2 fx = __builtin_elementwise_fma(s, log2ef, (f32x2)0.5f);
+    fx.x = __builtin_floorf(fx.x); fx.y = __builtin_floorf(fx.y);
+    const f32x2 r = __builtin_elementwise_fma(fx, nln2f, s);          // fma(-fx, ln2, s): negating an operand is exact
+    f32x2 p = __builtin_elementwise_fma(r, c5, c4);
+    p = __builtin_elementwise_fma(r, p, c3);
+    p = __builtin_elementwise_fma(r, p, c2);
+    p = __builtin_elementwise_fma(r, p, c1);
+    p = __builtin_elementwise_fma(r, p, (f32x2)1.0f);
+    const f32x2 fm1 = fx - (f32x2)1.0f;
+    f32x2 two_n;
+    two_n.x = below0 ? 0.0f : u2f((uint32_t)((int)fm1.x + 127) << 23);
+    two_n.y = below1 ? 0.0f : u2f((uint32_t)((int)fm1.y + 127) << 23);
+    p = p * two_n;
+    p = p * (f32x2)2.0f;
+    return p;
+}
+
 // ---- torch's cascade sum over the scored query rows (SumKernel.cpp multi_row_sum) -------------
 struct CascadeSum {
     float a0, a1, a2, a3;

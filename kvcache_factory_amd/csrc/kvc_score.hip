@@ -15,9 +15,6 @@
 //                    e = exp_u20(x - max), fixed-order partial sums (oracle: sum_kvc).
 //   pool_kernel    : one workgroup = 256 candidate keys (+ pooling halo): p = round(e / sum),
 //                    window sum in torch's cascade order, round, pool, write the scores.
-#include <stdlib.h>
-#include <string.h>
-
 #include "kvc_common.h"
 #include "kvc_launch.h"
 
@@ -481,7 +478,16 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const ScoreArgs a) {
     if (key < L) load_logits<DT, WV>(reinterpret_cast<const raw*>(vw.logits) + ((int64_t)hb * L + key) * W, W, x);
 #pragma unroll
     for (int w = 0; w < (WV > 0 ? WV : W); ++w) {
-        float e = (key < L) ? exp_u20(x[w] - m[w]) : 0.0f;
+        float e;
+        if constexpr (WV > 0) {                                    // two rows per packed-fp32 instruction
+            if ((w & 1) == 0) {
+                const f32x2 ex = exp_u20x2(f32x2{x[w], x[w + 1]} - f32x2{m[w], m[w + 1]});
+                x[w] = ex.x; x[w + 1] = ex.y;
+            }
+            e = (key < L) ? x[w] : 0.0f;
+        } else {
+            e = (key < L) ? exp_u20(x[w] - m[w]) : 0.0f;
+        }
         e = wave_xor_sum(e);
         if (lane == 0) wsum[wave * 64 + w] = e;
     }
@@ -538,7 +544,17 @@ __global__ __launch_bounds__(256) void pool_kernel(const ScoreArgs a) {
             CascadeSum cs;
             cs.init(W);
 #pragma unroll
-            for (int w = 0; w < (WV > 0 ? WV : W); ++w) cs.add(rnd<DT>(exp_u20(x[w] - m[w]) * rinv[w]));
+            for (int w = 0; w < (WV > 0 ? WV : W); ++w) {
+                if constexpr (WV > 0) {
+                    if ((w & 1) == 0) {
+                        const f32x2 pr = exp_u20x2(f32x2{x[w], x[w + 1]} - f32x2{m[w], m[w + 1]}) * f32x2{rinv[w], rinv[w + 1]};
+                        x[w] = pr.x; x[w + 1] = pr.y;
+                    }
+                    cs.add(rnd<DT>(x[w]));
+                } else {
+                    cs.add(rnd<DT>(exp_u20(x[w] - m[w]) * rinv[w]));
+                }
+            }
             sv = rnd<DT>(cs.result());
         }
         s_tile[t] = sv;
@@ -647,7 +663,11 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
                 const int key = it * SP_THREADS + tid;
                 float t[W];
 #pragma unroll
-                for (int w = 0; w < W; ++w) { e[it][w] = key < L ? exp_u20(x[it][w] - mr[w]) : 0.0f; t[w] = e[it][w]; }
+                for (int w = 0; w < W; w += 2) {
+                    const f32x2 ex = exp_u20x2(f32x2{x[it][w], x[it][w + 1]} - f32x2{mr[w], mr[w + 1]});
+                    e[it][w] = key < L ? ex.x : 0.0f; e[it][w + 1] = key < L ? ex.y : 0.0f;
+                    t[w] = e[it][w]; t[w + 1] = e[it][w + 1];
+                }
                 const float tot = wave_rows_sum<W>(t, lane);
                 if (lane < W) wsum[(it * 16 + wave) * W + my_row] = tot;
             }
@@ -658,7 +678,10 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
             float x[W], t[W];
             if (key < L) load_logits<DT, W>(lg + (int64_t)key * W, W, x);
 #pragma unroll
-            for (int w = 0; w < W; ++w) t[w] = key < L ? exp_u20(x[w] - mr[w]) : 0.0f;
+            for (int w = 0; w < W; w += 2) {
+                const f32x2 ex = exp_u20x2(f32x2{x[w], x[w + 1]} - f32x2{mr[w], mr[w + 1]});
+                t[w] = key < L ? ex.x : 0.0f; t[w + 1] = key < L ? ex.y : 0.0f;
+            }
             const float tot = wave_rows_sum<W>(t, lane);
             if (lane < W) wsum[(it * 16 + wave) * W + my_row] = tot;
         }
@@ -710,7 +733,11 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
         CascadeSum cs;
         cs.init(W);
 #pragma unroll
-        for (int w = 0; w < W; ++w) cs.add(rnd<DT>(ev[w] * ri[w]));
+        for (int w = 0; w < W; w += 2) {
+            const f32x2 pr = f32x2{ev[w], ev[w + 1]} * f32x2{ri[w], ri[w + 1]};
+            cs.add(rnd<DT>(pr.x));
+            cs.add(rnd<DT>(pr.y));
+        }
         return rnd<DT>(cs.result());
     };
     if constexpr (KEEP > 0) {
@@ -734,7 +761,10 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
                     float x[W], ev[W];
                     load_logits<DT, W>(lg + (int64_t)key * W, W, x);
 #pragma unroll
-                    for (int w = 0; w < W; ++w) ev[w] = exp_u20(x[w] - mr[w]);
+                    for (int w = 0; w < W; w += 2) {
+                        const f32x2 ex = exp_u20x2(f32x2{x[w], x[w + 1]} - f32x2{mr[w], mr[w + 1]});
+                        ev[w] = ex.x; ev[w + 1] = ex.y;
+                    }
                     sv = window_sum(ev);
                 }
                 seg[(it & 3) * SP_THREADS + tid] = sv;
@@ -750,22 +780,15 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
 // ---------------------------------------------------------------------------------------------
 // One workgroup per head (softmax_pool_kernel) when there are enough heads x items to fill the chip (a prompt's layers
 // batched: -25 % on the two kernels' time); the two-kernel split (many workgroups per head) otherwise — with 32 heads
-// the fused form would occupy 32 of 256 CUs.  Same bits either way; KVC_SOFTMAX_PATH=split|fused
-// forces one for the parity tests.
-static int softmax_path_override() {
-    static const int v = [] {
-        const char* e = getenv("KVC_SOFTMAX_PATH");
-        return !e ? 0 : (!strcmp(e, "split") ? 1 : (!strcmp(e, "fused") ? 2 : 0));
-    }();
-    return v;
-}
+// the fused form would occupy 32 of 256 CUs.  Same bits either way; debug_stage_mask bit3 / bit4 force split / fused
+// (parity tests).
 template <int DT, int WV>
 static void launch_softmax_pool_t(const ScoreArgs& a, hipStream_t st) {
-    const int m = a.stage_mask ? a.stage_mask : 7;
+    const int m = (a.stage_mask & 7) ? (a.stage_mask & 7) : 7;
     if constexpr (WV > 0) {
         const int iters = (a.q_len + SP_THREADS - 1) / SP_THREADS;
         const size_t lds = (size_t)(64 + 64 + 256 + 4 * SP_THREADS + (iters * 16 + a.n_chunks) * WV) * sizeof(float);
-        const int heads = a.bsz * a.n_q_heads * a.n_items, ov = softmax_path_override();
+        const int heads = a.bsz * a.n_q_heads * a.n_items, ov = (a.stage_mask & 8) ? 1 : ((a.stage_mask & 16) ? 2 : 0);
         const bool fits = lds <= 64 * 1024;
         const bool fused = fits && ov != 1 && (ov == 2 || heads >= 128);
         if (fused) {
@@ -796,7 +819,7 @@ static void launch_logits_t(const ScoreArgs& a, hipStream_t st) {
 
 template <int DT, int D, int WV>
 static void launch_all_t(const ScoreArgs& a, hipStream_t st) {
-    if ((a.stage_mask ? a.stage_mask : 7) & 1) {
+    if (((a.stage_mask & 7) ? (a.stage_mask & 7) : 7) & 1) {
         if constexpr (DT != KVC_FP32) {
             if (a.fast_dot) launch_logits_t<DT, D, WV, true>(a, st);
             else launch_logits_t<DT, D, WV, false>(a, st);

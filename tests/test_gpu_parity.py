@@ -330,3 +330,19 @@ def test_patched_model_on_gpu_layer_batching(kvc, gpu_device, method):
                               "maxpool" if method != "h2o" else None, pu.TIE_MODE, n_q_heads=32)
         assert la.keys.shape[2] == n_keep + W + 2 and torch.equal(la.keys[:, :, :n_keep + W], ko)
         assert torch.equal(la.values[:, :, :n_keep + W], vo)
+
+
+@pytest.mark.parametrize("name", ["snap_bf16_maxpool_W8_L1024_D128", "snap_fp16_avgpool_W32_L1024_D128", "snap_bf16_maxpool_W8_L257_D64",
+                                  "snap_bf16_avgpool_W32_L96_D128_peaky", "C2_snapkv_8k_bf16", "C2_snapkv_8k_fp16", "C2_snapkv_8k_bf16_W32",
+                                  "C5_pyramidkv_32k_layer0", "pyr_fp32_layer0_L1024", "edge_all_equal_scores_avg_fp32"])
+def test_softmax_pool_forms_identical(kvc, gpu_device, name):
+    """The softmax + window-sum + pooling stage has two forms — rowsum_kernel + pool_kernel (many workgroups per head)
+    and softmax_pool_kernel (one 1024-thread workgroup per head, exponentials kept in registers up to 8k keys,
+    recomputed beyond) — chosen by the number of heads in flight.  Same summation order: bit-identical scores, row
+    maxima and row sums."""
+    m = G.MANIFEST[name]
+    qd, kd, _ = G.inputs(m, device=gpu_device, expanded=False)
+    a = kvc.scores(kvc.SNAPKV, qd, kd, m["W"], m["kernel"], m["pooling"], want_intermediates=True, softmax_path="split")
+    b = kvc.scores(kvc.SNAPKV, qd, kd, m["W"], m["kernel"], m["pooling"], want_intermediates=True, softmax_path="fused")
+    assert torch.equal(G.bits(a[0]), G.bits(b[0]))
+    assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32)) and torch.equal(a[3].view(torch.int32), b[3].view(torch.int32))
