@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "kvc_common.h"
@@ -81,7 +82,11 @@ Layout carve(const kvc_params* p, int n_items = 1) {
         if (waves > tiles32) waves = tiles32;
         // a batch has parallelism to spare: give every wave ~4 tiles so the loads of tile t+1 overlap the MFMAs and the
         // epilogue of tile t (double-buffered LDS) instead of relying on occupancy alone
-        if ((int64_t)n_items * kvh * tiles32 >= 8192) waves = (tiles32 + 3) / 4;
+        if ((int64_t)n_items * kvh * tiles32 >= 8192) {
+            int tpw = 4;
+            if (const char* e = getenv("KVC_EXP_TPW")) tpw = atoi(e);
+            waves = (tiles32 + tpw - 1) / tpw;
+        }
         l.n_tiles = (waves + 3) / 4;                       // workgroups (4 waves each) per KV head == tile maxima per row
     }
     l.n_chunks = (int)((L + 255) / 256);

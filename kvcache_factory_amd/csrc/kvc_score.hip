@@ -15,6 +15,8 @@
 //                    e = exp_u20(x - max), fixed-order partial sums (oracle: sum_kvc).
 //   pool_kernel    : one workgroup = 256 candidate keys (+ pooling halo): p = round(e / sum),
 //                    window sum in torch's cascade order, round, pool, write the scores.
+#include <type_traits>
+
 #include "kvc_common.h"
 #include "kvc_launch.h"
 
@@ -121,29 +123,89 @@ template <int DT> __device__ __forceinline__ f32x16 mfma16(const uint4& av, cons
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, av), __builtin_bit_cast(h16x8, bv), acc, 0, 0, 0);
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N)
+template <int I0, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I0 < N) { f(std::integral_constant<int, I0>{}); static_for<I0 + 1, N>(f); }
+}
+// MFMA step STI of the exact bf16 scan: issue the LDS reads of its operands (not tracked by the compiler: pair with
+// wait_step before use).  A: chunk STI of the lane's fp32 fragment; B: bf16 elements 8*STI + 2s + kh, s = 0..3, widened by
+// the load (ds_read_u16_d16_hi clears the low half on gfx950: tools/d16_probe.hip).
+template <int STI> __device__ __forceinline__ void ld_step(f32x4& A, uint32_t (&B)[4], uint32_t arow_a, uint32_t krow_a) {
+    asm volatile("ds_read_b128 %0, %5 offset:%7\n\t"
+                 "ds_read_u16_d16_hi %1, %6 offset:%8\n\t"
+                 "ds_read_u16_d16_hi %2, %6 offset:%9\n\t"
+                 "ds_read_u16_d16_hi %3, %6 offset:%10\n\t"
+                 "ds_read_u16_d16_hi %4, %6 offset:%11"
+                 : "=v"(A), "=v"(B[0]), "=v"(B[1]), "=v"(B[2]), "=v"(B[3])
+                 : "v"(arow_a), "v"(krow_a), "n"(STI * 1024), "n"(STI * 16), "n"(STI * 16 + 4), "n"(STI * 16 + 8), "n"(STI * 16 + 12));
+}
+template <int N> __device__ __forceinline__ void wait_step(f32x4& A, uint32_t (&B)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(A), "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]) : "n"(N));
+}
+
+
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {       // byte address inside the workgroup's LDS
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+// Two values rounded to the storage dtype: the packed bits (element 0 in the low half) and the rounded values in fp32.
+template <int DT> __device__ __forceinline__ uint32_t pack2(f32x2 v, f32x2& back) {
+    if constexpr (DT == KVC_BF16) {
+        asm volatile("" : "+v"(v));                                   // round the fp32 values as such
+        const uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32
+        back.x = u2f(w << 16); back.y = u2f(w & 0xffff0000u);
+        return w;
+    } else {
+        const uint32_t lo = Dt<DT>::st(v.x), hi = Dt<DT>::st(v.y);
+        back.x = Dt<DT>::ld((uint16_t)lo); back.y = Dt<DT>::ld((uint16_t)hi);
+        return lo | (hi << 16);
+    }
+}
+template <int D> __device__ __forceinline__ f32x2 scale2_in_guard(f32x2 x, float c);   // ScaleDiv<D>::apply_in_guard x 2
+template <> __device__ __forceinline__ f32x2 scale2_in_guard<64>(f32x2 x, float) { return x * (f32x2)0.125f; }
+template <> __device__ __forceinline__ f32x2 scale2_in_guard<128>(f32x2 x, float c) {
+    const f32x2 rc = u2f(0x3db504f3u);
+    const f32x2 q0 = x * rc;
+    const f32x2 r = __builtin_elementwise_fma(-q0, (f32x2)c, x);
+    return __builtin_elementwise_fma(r, rc, q0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// logits_kernel (v5).  What shapes it: on gfx950 the f32-input MFMA and ordinary VALU instructions do NOT overlap on a
+// SIMD (tools/mfma_valu_probe.hip: chain + VALU costs the SUM of the two, even across waves), so every VALU
+// instruction of this kernel is paid in full on top of the 64-cycle MFMAs of the exact chain.  Hence:
+//   * bf16 K elements reach the MFMA B operand through ds_read_u16_d16_hi, which writes the 16 bits into the high
+//     half of the VGPR and clears the low half (tools/d16_probe.hip) — an exact bf16 -> fp32 widening with no VALU op;
+//   * LDS / global addresses are one per-lane register + immediate offsets (padded rows instead of an XOR swizzle,
+//     chunk-major A image, uniform bases in SGPRs);
+//   * the epilogue works on pairs with the packed-fp32 ALU, keeps one running maximum per accumulator register (the
+//     cross-lane fold happens once per wave, and the maximum is taken before the last rounding — rounding is monotonic).
+// ---------------------------------------------------------------------------------------------
 template <int DT, int D, int WV, bool FAST>
 __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreArgs a) {
     const ScoreView vw = view_of(a, blockIdx.z);
     typedef typename Dt<DT>::raw raw;
     constexpr int ES = Dt<DT>::esize;
     constexpr int ROWB = D * ES;             // bytes per key row
+    constexpr int ROWP = ROWB + 16;          // its pitch in LDS: the pad spreads the 32 keys of a column read over the banks
     constexpr int CH = ROWB / 16;            // 16-byte chunks per row
     constexpr int PAIRS = 8 / ES;            // mfma k-pairs per chunk: 4 (16-bit) or 2 (fp32)
-    constexpr int SWZ = CH < 16 ? CH - 1 : 15;
     constexpr int STG = CH / 2;              // staging registers (uint4) per lane per tile: 32*CH chunks / 64 lanes
-    constexpr int IMGROW = (D / 2) * 4;      // bytes of one lane's fp32 A-fragment (D/2 values)
-    constexpr int ICH = IMGROW / 16;         // its 16-byte chunks
-    constexpr int ISWZ = ICH < 16 ? ICH - 1 : 15;
+    constexpr int RPI = 64 / CH;             // key rows covered by one staging step
+    constexpr int ICH = D / 8;               // 16-byte chunks of one lane's fp32 A fragment (D/2 values)
+    constexpr bool ASM_B = (DT == KVC_BF16) && !FAST;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS: [Q image: 64 lanes x D/2 fp32, chunk-swizzled] [LOGITS_WAVES x 32-key tile] [LOGITS_WAVES x 32 floats]
+    // LDS: [Q image: ICH chunks x 64 lanes x 16 B] [LOGITS_WAVES x 32 keys x ROWP] [LOGITS_WAVES x 32 floats]
     char* const img = smem;
-    constexpr int nbuf = 1;                  // one K-tile buffer per wave: the next tile is parked in registers
-    constexpr int IMG_BYTES = FAST ? 0 : 64 * IMGROW;    // the FAST scan keeps its packed A fragments in registers
+    constexpr int IMG_BYTES = FAST ? 0 : 64 * ICH * 16;  // the FAST scan keeps its packed A fragments in registers
     constexpr int NSTEP = FAST ? D / 16 : ICH;            // MFMA steps per tile: D/16 (packed 16-deep) or one per A chunk
     char* const tiles = smem + IMG_BYTES;
-    float* wmax = reinterpret_cast<float*>(tiles + LOGITS_WAVES * nbuf * 32 * ROWB);   // [waves][32]
+    float* wmax = reinterpret_cast<float*>(tiles + LOGITS_WAVES * 32 * ROWP);   // [waves][32]
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: tile indices and bases stay in SGPRs
     const uint32_t psel = lane_sel<DT>(kh);
     const int b = blockIdx.y / a.n_kv_heads, g = blockIdx.y % a.n_kv_heads;
     const int L = a.q_len, W = WV > 0 ? WV : a.window, G = a.group;
@@ -151,34 +213,42 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
     const int n_mt = (rows + 31) / 32;
     const int n_t = (L + 31) / 32;            // 32-key tiles of this head
     const int wave_g = blockIdx.x * LOGITS_WAVES + wave, n_waves = gridDim.x * LOGITS_WAVES;
-    char* const buf = tiles + wave * (nbuf * 32 * ROWB);
+    char* const buf = tiles + wave * (32 * ROWP);
     const float sqrt_d = a.sqrt_d;
     KVC_STAMP(0);
 
-    const char* kbase = reinterpret_cast<const char*>(vw.k) +
-                        ((int64_t)b * a.k_stride_b + (int64_t)g * a.k_stride_h) * ES;
-    // chunk ids of this lane inside a tile: c = it*64 + lane -> row c / CH, chunk c % CH
-    auto issue = [&](int tile, uint4 (&st)[STG]) {
+    const char* const kbase = reinterpret_cast<const char*>(vw.k) +
+                              ((int64_t)b * a.k_stride_b + (int64_t)g * a.k_stride_h) * ES;
+    const int64_t tile_bytes = (int64_t)32 * a.k_stride_l * ES;    // one tile further along the key axis
+    uint32_t koff[STG];                                            // this lane's chunks inside a tile (global side)
 #pragma unroll
-        for (int it = 0; it < STG; ++it) {
-            const int c = it * 64 + lane, r = c / CH, cc = c % CH;
-            const int key = tile * 32 + r;
-            st[it] = key < L ? *reinterpret_cast<const uint4*>(kbase + (int64_t)key * a.k_stride_l * ES + cc * 16)
-                             : make_uint4(0, 0, 0, 0);
+    for (int it = 0; it < STG; ++it) {
+        const int c = it * 64 + lane;
+        koff[it] = (uint32_t)((c / CH) * (a.k_stride_l * ES) + (c % CH) * 16);
+    }
+    auto issue = [&](int tile, uint4 (&st)[STG]) {
+        const char* const tb = kbase + tile * tile_bytes;          // uniform
+        if (tile * 32 + 32 <= L) {
+#pragma unroll
+            for (int it = 0; it < STG; ++it) st[it] = *reinterpret_cast<const uint4*>(tb + koff[it]);
+        } else {
+#pragma unroll
+            for (int it = 0; it < STG; ++it) {
+                const int key = tile * 32 + it * RPI + lane / CH;
+                st[it] = key < L ? *reinterpret_cast<const uint4*>(tb + koff[it]) : make_uint4(0, 0, 0, 0);
+            }
         }
     };
-    auto commit = [&](char* dst, const uint4 (&st)[STG]) {
+    char* const cdst = buf + (lane / CH) * ROWP + (lane % CH) * 16;   // LDS side of the same chunks
+    auto commit = [&](const uint4 (&st)[STG]) {
 #pragma unroll
-        for (int it = 0; it < STG; ++it) {
-            const int c = it * 64 + lane, r = c / CH, cc = c % CH;
-            *reinterpret_cast<uint4*>(dst + r * ROWB + ((cc ^ (r & SWZ)) * 16)) = st[it];
-        }
+        for (int it = 0; it < STG; ++it) *reinterpret_cast<uint4*>(cdst + it * (RPI * ROWP)) = st[it];
     };
 
     for (int mt = 0; mt < n_mt; ++mt) {
         // ---- A operand: the workgroup converts the 32 query rows of this M-tile ONCE into an fp32 image in LDS, laid
-        // out as the MFMA A-fragment of every lane (lane = row + 32*parity, value s = Q[row][2s + parity]); the four
-        // waves then read their fragment chunk by chunk inside the MFMA loop instead of holding D/2 registers each.
+        // out as the MFMA A-fragment of every lane (lane = row + 32*parity, value s = Q[row][2s + parity]), chunk-major
+        // ([chunk][lane][4 values]) so that the waves read chunk c at one per-lane address + c*1024.
         uint4 st[STG];
         int tile = wave_g;
         if (tile < n_t) issue(tile, st);
@@ -211,17 +281,29 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
                 for (int sp = 0; sp < PAIRS; ++sp) {
                     const int sidx = cc * PAIRS + sp;
                     const int chunk = sidx >> 2, e = sidx & 3;
-                    *reinterpret_cast<float*>(img + r * IMGROW + ((chunk ^ (r & ISWZ)) * 16) + e * 4) = pick<DT>(v, sp, lane_sel<DT>(0));
-                    *reinterpret_cast<float*>(img + (32 + r) * IMGROW + ((chunk ^ ((32 + r) & ISWZ)) * 16) + e * 4) = pick<DT>(v, sp, lane_sel<DT>(1));
+                    *reinterpret_cast<float*>(img + chunk * 1024 + r * 16 + e * 4) = pick<DT>(v, sp, lane_sel<DT>(0));
+                    *reinterpret_cast<float*>(img + chunk * 1024 + (32 + r) * 16 + e * 4) = pick<DT>(v, sp, lane_sel<DT>(1));
                 }
             }
         }
         if (!FAST) __syncthreads();
-        if (tile < n_t) commit(buf, st);
+        if (tile < n_t) commit(st);
         KVC_STAMP(1);
-        float runmax = -__builtin_inff();     // running maximum of this lane's row (see reduce-scatter below)
-        const char* const krow = buf + j * ROWB;
-        const char* const arow = img + lane * IMGROW;
+        float rm[16];                          // running maximum per accumulator register (row 8*(e/4) + 4*kh + e%4)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rm[e] = -__builtin_inff();
+        const char* const krow = buf + j * ROWP;
+        const char* const arow = img + lane * 16;
+        const uint32_t krow_a = lds_addr(krow) + 2 * kh, arow_a = lds_addr(arow);
+        // logits of this lane: element (rg, e) of key `key` goes to lg + soff[rg] + key*W*ES (+ e*ES)
+        char* const lg = reinterpret_cast<char*>(vw.logits);
+        uint32_t soff[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int i0 = mt * 32 + 8 * rg + 4 * kh;
+            const int hq = g * G + (i0 < rows ? i0 / W : 0), w0 = i0 % W;
+            soff[rg] = (uint32_t)(((((int64_t)b * a.n_q_heads + hq) * L) * W + w0) * ES);
+        }
 
         // One epilogue element: the reference's three roundings (+ the local causal mask on the last W keys).
         auto finish = [&](float accv, int i, int key, bool tail) -> float {
@@ -232,9 +314,6 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
                 if (key >= L - W && (key - (L - W)) > w) v = rnd<DT>(v + Dt<DT>::finfo_min());
             }
             return v;
-        };
-        auto finish_plain = [&](float accv) -> float {         // same three roundings, no mask, no branch
-            return rnd<DT>(ScaleDiv<D>::apply_in_guard(rnd<DT>(accv), sqrt_d));
         };
         // Store 4 consecutive rows (one accumulator register group) of one key: 8 bytes (16-bit) or 16 bytes (fp32).
         auto store4 = [&](const float (&x)[4], int i0, int key) {
@@ -249,9 +328,9 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
                 *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
             }
         };
-        // per-row maximum over a tile's 32 keys: reduce-scatter over the 5 key bits (16 cross-lane moves): after the
+        // per-row maximum over the 32 key lanes: reduce-scatter over the 5 key bits (16 cross-lane moves): after the
         // step on lane bit t each lane keeps only the registers whose index bit matches its own.
-        auto fold_max = [&](const float (&xs)[16]) {
+        auto fold_max = [&](const float (&xs)[16]) -> float {
             const bool b4 = (j & 16) != 0, b3 = (j & 8) != 0, b2 = (j & 4) != 0, b1 = (j & 2) != 0;
             float y[8], z[4], u[2];
 #pragma unroll
@@ -275,13 +354,12 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
             float m = xor_lane<2>(b1 ? u[0] : u[1]);
             { const float keep = b1 ? u[1] : u[0]; m = m > keep ? m : keep; }
             { const float o = xor_lane<1>(m); m = o > m ? o : m; }
-            runmax = m > runmax ? m : runmax;
+            return m;
         };
         // General epilogue (ragged tile, masked tail, padded rows, W % 4 != 0): straight after its own MFMAs.
         auto epilogue_general = [&](const f32x16& acc, int t) {
             const int key = t * 32 + j;
             const bool tail = t * 32 + 32 > L - W;
-            float xs[16];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 float x[4];
@@ -289,7 +367,8 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     x[e] = finish(acc[rg * 4 + e], i0 + e, key, tail);
-                    xs[rg * 4 + e] = (key < L) ? x[e] : -__builtin_inff();
+                    const float xv = (key < L) ? x[e] : -__builtin_inff();
+                    rm[rg * 4 + e] = xv > rm[rg * 4 + e] ? xv : rm[rg * 4 + e];
                 }
                 if (i0 < rows && key < L) {
                     if ((W % 4) == 0) {
@@ -306,90 +385,136 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
                     }
                 }
             }
-            fold_max(xs);
         };
-        // A tile is "plain" when none of those cases applies: its epilogue is then branch-free and is interleaved, one
-        // accumulator element per A chunk, with the MFMA chain of the NEXT tile (the chain alone leaves the wave
-        // stalled on its 64-cycle dependency for most of its issue slots: SQ_WAIT_INST_ANY was 56 % of wave cycles).
+        // A tile is "plain" when none of those cases applies: its epilogue is then branch-free and rides, a pair of
+        // accumulator elements at a time, between the MFMA steps of the NEXT tile.
         const bool rows_plain = (W % 4) == 0 && (mt + 1) * 32 <= rows;
-        constexpr int EPC = 16 / NSTEP;       // accumulator elements of the previous tile finished per MFMA step
-        // MFMA step sti of the current tile.
-        auto mfma_step = [&](int sti, f32x16& acc) {
-            if constexpr (FAST) {
-                const uint4 kv = *reinterpret_cast<const uint4*>(krow + (((2 * sti + kh) ^ (j & SWZ)) * 16));
-                acc = mfma16<DT>(aq[sti], kv, acc);
-            } else {                                           // one A chunk = 4 fragment values = 4 exact f32 MFMAs
-                const float4 av = *reinterpret_cast<const float4*>(arow + ((sti ^ (lane & ISWZ)) * 16));
-                const float af[4] = {av.x, av.y, av.z, av.w};
-#pragma unroll
-                for (int kc = 0; kc < 4 / PAIRS; ++kc) {       // K chunks feeding these 4 values: 1 (16-bit) or 2 (fp32)
-                    const int c = sti * (4 / PAIRS) + kc;
-                    const uint4 kv = *reinterpret_cast<const uint4*>(krow + ((c ^ (j & SWZ)) * 16));
-#pragma unroll
-                    for (int s = 0; s < PAIRS; ++s)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc * PAIRS + s], pick<DT>(kv, s, psel), acc, 0, 0, 0);
-                }
+        // Plain epilogue of accumulator elements e0, e0+1 of the pending tile (rows i0+e0%4, +1 of register group e0/4).
+        uint32_t pkw[2];                                       // packed words of the current register group
+        auto plain_pair = [&](const f32x16& pend, int e0, uint32_t pkeyoff) {
+            if constexpr (DT == KVC_FP32) {
+                const float v0 = ScaleDiv<D>::apply_in_guard(pend[e0], sqrt_d), v1 = ScaleDiv<D>::apply_in_guard(pend[e0 + 1], sqrt_d);
+                rm[e0] = v0 > rm[e0] ? v0 : rm[e0];
+                rm[e0 + 1] = v1 > rm[e0 + 1] ? v1 : rm[e0 + 1];
+                *reinterpret_cast<float2*>(lg + (soff[e0 >> 2] + pkeyoff + (e0 & 3) * 4)) = make_float2(v0, v1);
+            } else {
+                f32x2 x = {pend[e0], pend[e0 + 1]}, back;
+                (void)pack2<DT>(x, back);                                         // first rounding
+                const f32x2 q = scale2_in_guard<D>(back, sqrt_d);                 // second: after the scaling
+                rm[e0] = __builtin_fmaxf(rm[e0], q.x);                            // (maximum before rounding: monotonic)
+                rm[e0 + 1] = __builtin_fmaxf(rm[e0 + 1], q.y);
+                f32x2 unused;
+                pkw[(e0 >> 1) & 1] = pack2<DT>(q, unused);
+                if ((e0 & 3) == 2) *reinterpret_cast<uint2*>(lg + (soff[e0 >> 2] + pkeyoff)) = make_uint2(pkw[0], pkw[1]);
             }
         };
+        constexpr int EPC = 16 / NSTEP;       // accumulator elements of the previous tile per MFMA step (1, 2 or 4)
         f32x16 pend = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         int ptile = -1;                        // tile whose (plain) epilogue is still pending
         for (; tile < n_t; tile += n_waves) {
             const int next = tile + n_waves;
+#if defined(KVC_EXP_NO_GLOAD)
+            if (next < n_t && a.q_len < 0) issue(next, st);
+#else
             if (next < n_t) issue(next, st);                  // in flight during the MFMAs below
+#endif
             __builtin_amdgcn_wave_barrier();
             KVC_STAMP(2);
             // ---- 32 rows x 32 keys, chain over d = 0..D-1 in order ----
             f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            if (ptile >= 0) {
-                const int pkey = ptile * 32 + j;
-                float xs[16], x[4];
+            const uint32_t pkeyoff = (uint32_t)(ptile * 32 + j) * (uint32_t)(W * ES);
+            // the pairs of the pending tile that ride behind MFMA step ic
+            auto ride = [&](auto ic_) {
+                constexpr int ic = decltype(ic_)::value;
 #pragma unroll
-                for (int ic = 0; ic < NSTEP; ++ic) {
-                    mfma_step(ic, acc);
+                for (int pr = (ic * EPC) / 2; pr < ((ic + 1) * EPC) / 2; ++pr) plain_pair(pend, 2 * pr, pkeyoff);
+            };
+            auto chain = [&](auto withp_) {
+                constexpr bool withp = decltype(withp_)::value;
+                if constexpr (ASM_B) {
+                    // operands by hand-issued LDS reads, one step ahead of the MFMAs that consume them:
+                    //   A: 4 fragment values (ds_read_b128, chunk-major image);  B: 4 x bf16 -> fp32 in the load itself.
+                    asm volatile("" ::: "memory");            // this tile's ds_writes (commit) stay above the reads
+                    f32x4 A0, A1;
+                    uint32_t B0[4], B1[4];
+                    ld_step<0>(A0, B0, arow_a, krow_a);
+                    static_for<0, NSTEP>([&](auto ic_) {
+                        constexpr int ic = decltype(ic_)::value;
+                        f32x4& Ac = (ic & 1) ? A1 : A0;
+                        uint32_t (&Bc)[4] = (ic & 1) ? B1 : B0;
+                        if constexpr (ic + 1 < NSTEP) {
+#if defined(KVC_EXP_NO_LDS)
+                            if (a.q_len < 0)
+#endif
+                            ld_step<ic + 1>((ic & 1) ? A0 : A1, (ic & 1) ? B0 : B1, arow_a, krow_a);
+                            wait_step<5>(Ac, Bc);             // all but the 5 reads just issued have landed
+                        } else {
+                            wait_step<0>(Ac, Bc);
+                        }
 #pragma unroll
-                    for (int q = 0; q < EPC; ++q) {            // previous tile's element e rides in this chain's shadow
-                        const int e = ic * EPC + q;
-                        const int i0 = mt * 32 + 8 * (e >> 2) + 4 * kh;
-                        const float v = finish_plain(pend[e]);
-                        x[e & 3] = v;
-                        xs[e] = v;
-                        if ((e & 3) == 3) store4(x, i0, pkey);
-                    }
-                    // ask the scheduler to lay this chunk out as MFMA, ~10 VALU, MFMA, ... instead of 4 back-to-back
-                    // dependent MFMAs followed by the element's VALU block
+                        for (int s4 = 0; s4 < 4; ++s4)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[s4], u2f(Bc[s4]), acc, 0, 0, 0);
+                        if constexpr (withp) ride(ic_);
+                    });
+                    asm volatile("" ::: "memory");            // ... and the next tile's ds_writes stay below them
+                } else {
+                    static_for<0, NSTEP>([&](auto ic_) {
+                        constexpr int sti = decltype(ic_)::value;
+                        if constexpr (FAST) {
+                            const uint4 kv = *reinterpret_cast<const uint4*>(krow + (2 * sti + kh) * 16);
+                            acc = mfma16<DT>(aq[sti], kv, acc);
+                        } else {                               // one A chunk = 4 fragment values = 4 exact f32 MFMAs
+                            const float4 av = *reinterpret_cast<const float4*>(arow + sti * 1024);
+                            const float af[4] = {av.x, av.y, av.z, av.w};
 #pragma unroll
-                    for (int q = 0; q < (FAST ? 1 : 4); ++q) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, FAST ? 40 : 10, 0);
-                    }
+                            for (int kc = 0; kc < 4 / PAIRS; ++kc) {   // K chunks feeding these 4 values: 1 (16-bit) or 2 (fp32)
+                                const int c = sti * (4 / PAIRS) + kc;
+                                const uint4 kv = *reinterpret_cast<const uint4*>(krow + c * 16);
+#pragma unroll
+                                for (int sp = 0; sp < PAIRS; ++sp)
+                                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc * PAIRS + sp], pick<DT>(kv, sp, psel), acc, 0, 0, 0);
+                            }
+                        }
+                        if constexpr (withp) ride(ic_);
+                    });
                 }
-                fold_max(xs);
-                ptile = -1;
-            } else {
-#pragma unroll
-                for (int ic = 0; ic < NSTEP; ++ic) mfma_step(ic, acc);
-            }
+            };
+            if (ptile >= 0) { chain(std::true_type{}); ptile = -1; }
+            else chain(std::false_type{});
             asm volatile("" :: "v"(acc[0]), "v"(acc[15]));
             // the tile's LDS reads are all issued (the LDS serves a wave in order): the next tile may overwrite the single
             // buffer now, so its ds_writes overlap the VALU work that follows
-            if (next < n_t) commit(buf, st);
+            if (next < n_t) commit(st);
             KVC_STAMP(3);
             bool plain = rows_plain && tile * 32 + 32 <= L - W && next < n_t;
             if (plain) {
                 // the branch-free scaling needs every |value| of the tile inside [2^-98, 2^126] (rounding to dtype moves a
-                // value by < 1 %, so this keeps the rounded value inside the proven [2^-100, inf) guard); a zero logit or
-                // an overflow sends the whole tile down the general path instead
-                float amin = __builtin_fabsf(acc[0]), amax = amin;
+                // value by < 1 %, so this keeps the rounded value inside the proven [2^-100, inf) guard); a zero logit, an
+                // overflow or a NaN sends the whole tile down the general path instead
+                uint32_t amin = f2u(acc[0]) & 0x7fffffffu, amax = amin;
 #pragma unroll
-                for (int e = 1; e < 16; ++e) { const float t = __builtin_fabsf(acc[e]); amin = t < amin ? t : amin; amax = t > amax ? t : amax; }
-                plain = !__any(!(amin >= u2f(0x0e800000u) && amax <= u2f(0x7e800000u)));
+                for (int e = 1; e < 16; ++e) {
+                    const uint32_t t = f2u(acc[e]) & 0x7fffffffu;
+                    amin = t < amin ? t : amin;
+                    amax = t > amax ? t : amax;
+                }
+                plain = !__any(!(amin >= 0x0e800000u && amax <= 0x7e800000u));
             }
+#if defined(KVC_EXP_NO_EPI)
+            if (!plain) epilogue_general(acc, tile);
+            else if (a.q_len < 0) { pend = acc; ptile = tile; }
+#else
             if (plain) { pend = acc; ptile = tile; }           // finished under the next tile's MFMAs
             else epilogue_general(acc, tile);
+#endif
             KVC_STAMP(5);
         }
         // ---- block-level maximum per row -> pmax[hq][blockIdx.x][w] ----
         {
+            float rmr[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) rmr[e] = rnd<DT>(rm[e]);  // plain tiles kept the unrounded value (monotonic)
+            const float runmax = fold_max(rmr);
             const int R = ((j >> 1) & 1) + ((j >> 2) & 1) * 2 + ((j >> 3) & 1) * 4 + ((j >> 4) & 1) * 8;   // accumulator register
             if ((j & 1) == 0) wmax[wave * 32 + (R & 3) + 8 * (R >> 2) + 4 * kh] = runmax;
         }
@@ -810,7 +935,7 @@ static void launch_softmax_pool_t(const ScoreArgs& a, hipStream_t st) {
 template <int DT, int D, int WV, bool FAST>
 static void launch_logits_t(const ScoreArgs& a, hipStream_t st) {
     constexpr int ES = Dt<DT>::esize;
-    const size_t lds = (FAST ? 0 : (size_t)64 * (D / 2) * 4) + (size_t)LOGITS_WAVES * 32 * D * ES + LOGITS_WAVES * 32 * sizeof(float);
+    const size_t lds = (FAST ? 0 : (size_t)64 * (D / 2) * 4) + (size_t)LOGITS_WAVES * 32 * (D * ES + 16) + LOGITS_WAVES * 32 * sizeof(float);
     static LdsCache lds_cache = {};
     (void)ensure_lds(reinterpret_cast<const void*>(&logits_kernel<DT, D, WV, FAST>), lds, lds_cache);   // a failure surfaces as a launch error
     dim3 g1((unsigned)a.n_tiles, (unsigned)(a.bsz * a.n_kv_heads), (unsigned)a.n_items);
