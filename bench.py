@@ -223,7 +223,7 @@ def time_scan_kernel_batch(bstep, dev, reps=10):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-def cpu_baseline(cfg, budget_s=12.0):
+def cpu_baseline(cfg, budget_s=12.0, dev=None):
     """The CPU oracle (a port of the reference's algorithm, oracle/kvc_oracle.cpp) timed on this host's cores on a
     bounded sample of the same workload: whole layer calls of the bench config, repeated for ~budget_s seconds."""
     from oracle import kvc_oracle as O      # cpu_baseline leg only (the checker, timed as the baseline)
@@ -272,6 +272,24 @@ def cpu_baseline(cfg, budget_s=12.0):
         out["torch_cpu_ops_threads"] = threads
     except Exception as e:  # pragma: no cover
         out["torch_cpu_ops_error"] = repr(e)
+    # parity counters on the same layer: the HIP path against the oracle's product arithmetic, both tie modes
+    try:
+        if dev is not None and cfg["method"] != "h2o":
+            qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+            par = {}
+            for tie, otie in (("canonical", O.TIES_CANON), ("torch_cpu", O.TIES_TORCH)):
+                ko, vo, idx, sc = O.compress(q, k, v, cfg["W"], n_keep, cfg["kernel"], cfg["pooling"], dot_mode=O.DOT_CHAIN,
+                                             sum_mode=O.SUM_KVC, tie_mode=otie, n_threads=threads)
+                g = _kvc.compress(METHODS[cfg["method"]], qd, kd, vd, cfg["W"], n_keep, cfg["kernel"], cfg["pooling"], tie,
+                                  return_indices=True, return_scores=True)
+                gi, gs = g[2][0].cpu(), g[3][0].cpu()
+                par[tie] = {"score_bits_differing": int((gs.view(torch.int16) != sc.view(torch.int16)).sum()),
+                            "scores_compared": int(sc.numel()),
+                            "heads_with_identical_indices": int((gi == idx).all(dim=1).sum()), "heads": int(idx.shape[0]),
+                            "k_out_v_out_bytes_equal": bool(torch.equal(g[0].cpu(), ko) and torch.equal(g[1].cpu(), vo))}
+            out["parity_vs_oracle_same_layer"] = par
+    except Exception as e:  # pragma: no cover
+        out["parity_error"] = repr(e)
     return out
 
 
@@ -429,7 +447,7 @@ def main():
                 extra["expanded_kv_error"] = str(e)
             out["extras"] = extra
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+            out["cpu_baseline"] = cpu_baseline(cfg, dev=dev)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -189,13 +189,17 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
     typedef typename Dt<DT>::raw raw;
     constexpr int ES = Dt<DT>::esize;
     constexpr int ROWB = D * ES;             // bytes per key row
-    constexpr int ROWP = ROWB + 16;          // its pitch in LDS: the pad spreads the 32 keys of a column read over the banks
+    constexpr bool ASM_B = (DT == KVC_BF16) && !FAST;
+    // Row pitch in LDS.  The exact bf16 scan reads ONE dword per key row per instruction (ds_read_u16_d16_hi): an odd
+    // dword pitch puts the 32 keys in 32 different banks (a 16-byte pad left 4-way conflicts: SQ_LDS_BANK_CONFLICT was
+    // 24 % of the kernel's cycles); the rows are then only 4-byte aligned and are staged with dword-pair writes.  The
+    // other variants read 16-byte chunks and keep 16-byte aligned rows.
+    constexpr int ROWP = ASM_B ? ROWB + 4 : ROWB + 16;
     constexpr int CH = ROWB / 16;            // 16-byte chunks per row
     constexpr int PAIRS = 8 / ES;            // mfma k-pairs per chunk: 4 (16-bit) or 2 (fp32)
     constexpr int STG = CH / 2;              // staging registers (uint4) per lane per tile: 32*CH chunks / 64 lanes
     constexpr int RPI = 64 / CH;             // key rows covered by one staging step
     constexpr int ICH = D / 8;               // 16-byte chunks of one lane's fp32 A fragment (D/2 values)
-    constexpr bool ASM_B = (DT == KVC_BF16) && !FAST;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS: [Q image: ICH chunks x 64 lanes x 16 B] [LOGITS_WAVES x 32 keys x ROWP] [LOGITS_WAVES x 32 floats]
     char* const img = smem;
@@ -242,7 +246,14 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
     char* const cdst = buf + (lane / CH) * ROWP + (lane % CH) * 16;   // LDS side of the same chunks
     auto commit = [&](const uint4 (&st)[STG]) {
 #pragma unroll
-        for (int it = 0; it < STG; ++it) *reinterpret_cast<uint4*>(cdst + it * (RPI * ROWP)) = st[it];
+        for (int it = 0; it < STG; ++it) {
+            if constexpr (ASM_B) {
+                uint32_t* d = reinterpret_cast<uint32_t*>(cdst + it * (RPI * ROWP));
+                d[0] = st[it].x; d[1] = st[it].y; d[2] = st[it].z; d[3] = st[it].w;
+            } else {
+                *reinterpret_cast<uint4*>(cdst + it * (RPI * ROWP)) = st[it];
+            }
+        }
     };
 
     for (int mt = 0; mt < n_mt; ++mt) {
