@@ -212,7 +212,7 @@ def select(scores_t, n_keep, tie_mode="torch_cpu"):
     idx = torch.empty(scores_t.shape[0], scores_t.shape[1], n_keep, dtype=torch.int64, device=scores_t.device)
     ws, nbytes = None, 0
     if p.tie_mode == TIES_TORCH_CPU:      # the exact path may keep its (key, index) array in the workspace
-        nbytes = scores_t.shape[0] * scores_t.shape[1] * scores_t.shape[2] * 8 + 256
+        nbytes = scores_t.shape[0] * scores_t.shape[1] * (scores_t.shape[2] + scores_t.shape[2] // 2 + 2) * 8 + 256
         ws = workspace(scores_t.device, nbytes)
     _check(lib().kvc_select(ctypes.byref(p), _ptr(scores_t), _ptr(idx), _ptr(ws), nbytes, _stream(scores_t.device)))
     return idx

@@ -129,6 +129,138 @@ __device__ __forceinline__ void partial_sort_wave(const typename Dt<DT>::raw* s,
     for (int t = lane; t < k; t += 64) out[t] = (int64_t)(res[t] & 0xffffffffull);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// nth_element + sort regime, one wavefront: the same moves as kvc_stl_emul.h, with the two loops that dominate made
+// lane-parallel.
+//
+// __unguarded_partition(first, last, pivot): the serial scans pair the t-th element from the left that does not sort
+// before the pivot (key <= pk, a "left stopper") with the t-th element from the right that the pivot does not sort
+// before (key >= pk, a "right stopper") and swap them for as long as left < right.  Positions between the two cursors
+// are untouched while that goes on, so both stopper sequences can be read off the ORIGINAL array: T = number of t with
+// l_t < r_t, swap those pairs, and the returned cut is min(l_{T+1}, r_T) (the left scan stops at the next original
+// stopper or, if it gets there first, at r_T, which now holds a left stopper).  Two compaction passes build the
+// position lists (caller's scratch, <= m/2 + 2 entries each), one pass swaps.
+//
+// __final_insertion_sort after the introsort loop: insertion sort is stable, and every unsorted run left by the loop
+// is at most 16 long with runs already ordered among themselves, so the final place of element i is
+// i - #(j in [i-15, i): key_j < key_i) + #(j in (i, i+15]: key_j > key_i) — 30 reads per element, all lanes at once.
+// ---------------------------------------------------------------------------------------------------------
+struct WaveSel {
+    u64* arr;
+    int* Lp;
+    int* Rp;
+    int lane;
+    __device__ __forceinline__ static uint32_t key(u64 v) { return (uint32_t)(v >> 32); }
+    __device__ __forceinline__ u64 get(int i) const { return uni(arr[i]); }
+
+    __device__ int partition(int first, int last, int pivot) {
+        const uint32_t pk = key(get(pivot));
+        const int cap = (last - first) / 2 + 2;
+        int NL = 0, NR = 0;
+        for (int base = first; base < last; base += 64) {                 // left stoppers, ascending positions
+            const int i = base + lane;
+            const bool sl = i < last && !(key(arr[i]) > pk);
+            const u64 mask = __ballot(sl);
+            const int rank = NL + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+            if (sl && rank < cap) Lp[rank] = i;
+            NL += __builtin_popcountll(mask);
+        }
+        for (int top = last; top > first; top -= 64) {                    // right stoppers, descending positions
+            const int i = top - 1 - lane;
+            const bool sr = i >= first && !(pk > key(arr[i]));
+            const u64 mask = __ballot(sr);
+            const int rank = NR + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+            if (sr && rank < cap) Rp[rank] = i;
+            NR += __builtin_popcountll(mask);
+        }
+        __syncthreads();
+        int lim = NL < NR ? NL : NR;
+        if (lim > cap) lim = cap;
+        int T = 0;
+        for (int t0 = 0; t0 < lim; t0 += 64) {                            // l_t < r_t holds for a prefix of t
+            const int t = t0 + lane;
+            const bool ok = t < lim && Lp[t] < Rp[t];
+            const u64 bad = ~__ballot(ok);
+            if (bad == 0) { T += 64; continue; }
+            T += __builtin_ctzll(bad);
+            break;
+        }
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < T) { const int l = Lp[t], r = Rp[t]; const u64 a = arr[l], b = arr[r]; arr[l] = b; arr[r] = a; }
+        }
+        const int lnext = T < NL ? uni(Lp[T]) : 0x7fffffff;
+        const int rlast = T > 0 ? uni(Rp[T - 1]) : 0x7fffffff;
+        __syncthreads();
+        return lnext < rlast ? lnext : rlast;
+    }
+    __device__ int partition_pivot(int first, int last) {                 // __unguarded_partition_pivot
+        const int mid = first + (last - first) / 2;
+        Arr A{arr};
+        if (lane == 0) move_median_to_first_(A, first, first + 1, mid, last - 1);
+        __syncthreads();
+        return partition(first + 1, last, first);
+    }
+    __device__ void introselect(int first, int nth, int last, int depth_limit) {
+        Arr A{arr};
+        while (last - first > 3) {
+            if (depth_limit == 0) {
+                heap_select_(A, first, nth + 1, last);
+                A.swap(first, nth);
+                __syncthreads();
+                return;
+            }
+            --depth_limit;
+            const int cut = partition_pivot(first, last);
+            if (cut <= nth) first = cut; else last = cut;
+        }
+        insertion_sort_(A, first, last);
+        __syncthreads();
+    }
+    // std::sort(first, last) whose result goes straight to out[first..last) as indices
+    __device__ void sort_to(int first, int last, int* stack, int64_t* out) {
+        if (first == last) return;
+        Arr A{arr};
+        int sp = 0;
+        int f = first, l = last, d = lg_(last - first) * 2;
+        while (true) {
+            while (l - f > 16) {
+                if (d == 0) {
+                    heap_select_(A, f, l, l);
+                    sort_heap_(A, f, l);
+                    __syncthreads();
+                    break;
+                }
+                --d;
+                const int cut = partition_pivot(f, l);
+                if (lane == 0) { stack[3 * sp] = cut; stack[3 * sp + 1] = l; stack[3 * sp + 2] = d; }
+                ++sp;
+                l = cut;
+            }
+            if (sp == 0) break;
+            --sp;
+            __syncthreads();
+            f = uni(stack[3 * sp]); l = uni(stack[3 * sp + 1]); d = uni(stack[3 * sp + 2]);
+        }
+        __syncthreads();
+        for (int base = first; base < last; base += 64) {                  // __final_insertion_sort, all elements at once
+            const int i = base + lane;
+            if (i < last) {
+                const u64 v = arr[i];
+                const uint32_t ki = key(v);
+                int pos = i;
+#pragma unroll 5
+                for (int dlt = 1; dlt < 16; ++dlt) {
+                    const int jb = i - dlt, ja = i + dlt;
+                    if (jb >= first && key(arr[jb]) < ki) --pos;
+                    if (ja < last && key(arr[ja]) > ki) ++pos;
+                }
+                out[pos] = (int64_t)(v & 0xffffffffull);
+            }
+        }
+    }
+};
+
 constexpr int kWaveHeapMaxK = 128;
 constexpr size_t kWaveHeapLds = (192 + 128) * 8;
 
@@ -174,23 +306,26 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const SelectArgs a, u6
         __syncthreads();
         for (int t = lane; t < k; t += 64) out[t] = (int64_t)(lds_arr[t] & 0xffffffffull);
     } else {
-        u64* arr = arr_in_lds ? lds_arr : gscratch + ((int64_t)item * a.heads + head) * n;
+        // scratch per (item, head): [n u64 array, when it does not fit in LDS][2 x (n/2 + 2) int position lists]
+        const int64_t per_head = (arr_in_lds ? 0 : (int64_t)n) + (n / 2 + 2);
+        u64* const hs = gscratch + ((int64_t)item * a.heads + head) * per_head;
+        u64* arr = arr_in_lds ? lds_arr : hs;
+        int* const lists = reinterpret_cast<int*>(hs + (arr_in_lds ? 0 : n));
         for (int i = lane; i < n; i += 64) arr[i] = ((u64)Key<DT>::of(s[i]) << 32) | (uint32_t)i;
         __syncthreads();
-        Arr A{arr};
+        WaveSel S{arr, lists, lists + (n / 2 + 2), lane};
         // std::nth_element(first, first + k - 1, last)
-        if (k - 1 != n) introselect_(A, 0, k - 1, n, lg_(n) * 2);
-        // std::sort(first, first + k - 1)
-        sort_(A, 0, k - 1, stack);
-        __syncthreads();
-        for (int t = lane; t < k; t += 64) out[t] = (int64_t)(arr[t] & 0xffffffffull);
+        if (k - 1 != n) S.introselect(0, k - 1, n, lg_(n) * 2);
+        // std::sort(first, first + k - 1), written to out as it is placed; the nth element follows
+        S.sort_to(0, k - 1, stack, out);
+        if (lane == 0) out[k - 1] = (int64_t)(arr[k - 1] & 0xffffffffull);
     }
 }
 
 size_t select_exact_scratch_bytes(int heads, int n, int k) {
     const bool partial = (int64_t)k * 64 <= (int64_t)n;
-    if (partial || n <= 18000) return 0;
-    return (size_t)heads * n * 8;
+    if (partial) return 0;
+    return (size_t)heads * ((n <= 18000 ? 0 : (size_t)n) + (size_t)(n / 2 + 2)) * 8;
 }
 
 template <int DT>
@@ -201,7 +336,7 @@ static int launch_exact_t(const SelectArgs& a, void* scratch, hipStream_t st) {
     const int in_lds = !any_nth || a.n <= 18000;
     const size_t elems = in_lds ? (any_nth ? (size_t)a.n : (size_t)a.k_max) : (size_t)a.k_max;
     const size_t lds = 1152 + (elems * 8 > kWaveHeapLds ? elems * 8 : kWaveHeapLds);
-    if (!in_lds && !scratch) return KVC_ERR_WORKSPACE;
+    if (any_nth && !scratch) return KVC_ERR_WORKSPACE;
     static LdsCache lds_cache = {};
     if (ensure_lds(reinterpret_cast<const void*>(&select_exact_kernel<DT>), lds, lds_cache) != 0) return KVC_ERR_HIP;
     hipLaunchKernelGGL((select_exact_kernel<DT>), dim3((unsigned)a.heads, (unsigned)a.n_items), dim3(64), lds, st, a,
