@@ -91,7 +91,6 @@ Layout carve(const kvc_params* p, int n_items = 1) {
             const double cost = (double)rounds * (tpw + 1.5);                   // 1.5 tiles' worth of prologue per workgroup
             if (cost < best - 1e-9) { best = cost; best_g = g; }
         }
-        if (const char* e = getenv("KVC_EXP_TPW")) { const int tpw = atoi(e); if (tpw > 0) best_g = (tiles32 + 4 * tpw - 1) / (4 * tpw); }
         l.n_tiles = best_g;                                // workgroups (4 waves each) per KV head == tile maxima per row
     }
     l.n_chunks = (int)((L + 255) / 256);

@@ -424,11 +424,7 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
         int ptile = -1;                        // tile whose (plain) epilogue is still pending
         for (; tile < n_t; tile += n_waves) {
             const int next = tile + n_waves;
-#if defined(KVC_EXP_NO_GLOAD)
-            if (next < n_t && a.q_len < 0) issue(next, st);
-#else
             if (next < n_t) issue(next, st);                  // in flight during the MFMAs below
-#endif
             __builtin_amdgcn_wave_barrier();
             KVC_STAMP(2);
             // ---- 32 rows x 32 keys, chain over d = 0..D-1 in order ----
@@ -454,9 +450,6 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
                         f32x4& Ac = (ic & 1) ? A1 : A0;
                         uint32_t (&Bc)[4] = (ic & 1) ? B1 : B0;
                         if constexpr (ic + 1 < NSTEP) {
-#if defined(KVC_EXP_NO_LDS)
-                            if (a.q_len < 0)
-#endif
                             ld_step<ic + 1>((ic & 1) ? A0 : A1, (ic & 1) ? B0 : B1, arow_a, krow_a);
                             wait_step<5>(Ac, Bc);             // all but the 5 reads just issued have landed
                         } else {
@@ -511,13 +504,8 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
                 }
                 plain = !__any(!(amin >= 0x0e800000u && amax <= 0x7e800000u));
             }
-#if defined(KVC_EXP_NO_EPI)
-            if (!plain) epilogue_general(acc, tile);
-            else if (a.q_len < 0) { pend = acc; ptile = tile; }
-#else
             if (plain) { pend = acc; ptile = tile; }           // finished under the next tile's MFMAs
             else epilogue_general(acc, tile);
-#endif
             KVC_STAMP(5);
         }
         // ---- block-level maximum per row -> pmax[hq][blockIdx.x][w] ----

@@ -27,22 +27,40 @@ namespace kvc {
 // the nodes so a lane can fetch its children; xl/xr cache them.  M bit p = 1  <=>  __adjust_heap at node p moves to
 // the LEFT child (comp(a[2p+2], a[2p+1]), or p has only a left child).
 // ---------------------------------------------------------------------------------------------------------
-struct WaveHeap {
-    u64 lo, hi;            // node values
-    u64 xl, xr;            // children of node `lane`
-    u64 A_lo, R_lo, A_hi, R_hi;   // ancestors of the node(s) and the M bits they must show for the node to be reached
-    u64 M;                 // wave-uniform
-    u64* arr;
-    int lane;
-
+// Node word: (key << 32 | index) in 64 bits, or — 16-bit dtypes, n <= 65536 — (key << 16 | index) in 32 bits, which
+// halves every move, compare and LDS access of the heap.
+template <class NT> struct HeapNode;
+template <> struct HeapNode<u64> {
+    __device__ __forceinline__ static u64 make(uint32_t key, int idx) { return ((u64)key << 32) | (uint32_t)idx; }
+    __device__ __forceinline__ static bool gt(u64 a, u64 b) { return (uint32_t)(a >> 32) > (uint32_t)(b >> 32); }      // key(a) > key(b)
     __device__ __forceinline__ static uint32_t key(u64 v) { return (uint32_t)(v >> 32); }
+    __device__ __forceinline__ static int64_t index(u64 v) { return (int64_t)(v & 0xffffffffull); }
     __device__ __forceinline__ static u64 rdlane(u64 v, int l) {
         const uint32_t a = __builtin_amdgcn_readlane((uint32_t)v, l), b = __builtin_amdgcn_readlane((uint32_t)(v >> 32), l);
         return ((u64)b << 32) | a;
     }
-    __device__ __forceinline__ u64 node(int i) const { return i < 64 ? rdlane(lo, i) : rdlane(hi, i - 64); }
+};
+template <> struct HeapNode<uint32_t> {
+    __device__ __forceinline__ static uint32_t make(uint32_t key, int idx) { return (key << 16) | (uint32_t)idx; }
+    __device__ __forceinline__ static bool gt(uint32_t a, uint32_t b) { return a > (b | 0xffffu); }                    // key(a) > key(b)
+    __device__ __forceinline__ static uint32_t key(uint32_t v) { return v >> 16; }
+    __device__ __forceinline__ static int64_t index(uint32_t v) { return (int64_t)(v & 0xffffu); }
+    __device__ __forceinline__ static uint32_t rdlane(uint32_t v, int l) { return __builtin_amdgcn_readlane(v, l); }
+};
 
-    __device__ __forceinline__ void init(u64* lds, int len) {       // lo/hi set by the caller; arr[0..191] is ours
+template <class NT>
+struct WaveHeap {
+    typedef HeapNode<NT> N;
+    NT lo, hi;             // node values
+    NT xl, xr;             // children of node `lane`
+    u64 A_lo, R_lo, A_hi, R_hi;   // ancestors of the node(s) and the M bits they must show for the node to be reached
+    u64 M;                 // wave-uniform
+    NT* arr;
+    int lane;
+
+    __device__ __forceinline__ NT node(int i) const { return i < 64 ? N::rdlane(lo, i) : N::rdlane(hi, i - 64); }
+
+    __device__ __forceinline__ void init(NT* lds, int len) {        // lo/hi set by the caller; arr[0..191] is ours
         lane = threadIdx.x;
         arr = lds;
         A_lo = R_lo = A_hi = R_hi = 0;
@@ -51,47 +69,59 @@ struct WaveHeap {
         arr[lane] = lo; arr[lane + 64] = hi; arr[lane + 128] = 0;
         __syncthreads();
         xl = arr[2 * lane + 1]; xr = arr[2 * lane + 2];
-        M = __ballot(key(xr) > key(xl));
+        M = __ballot(N::gt(xr, xl));
         set_len(len);
     }
     __device__ __forceinline__ void set_len(int len) {               // a node with only a left child moves left
         if (len >= 2 && (len & 1) == 0) M |= 1ull << ((len - 2) >> 1);
     }
-    // __adjust_heap(first, t, len, value) + its __push_heap, all levels at once.  At = ancestors of t (0 for t = 0).
-    __device__ __forceinline__ void adjust(int t, u64 At, int len, u64 value) {
-        const bool on_lo = lane < len && (lane == t || (((A_lo >> t) & 1) && (((M ^ R_lo) & A_lo & ~At) == 0)));
-        const bool on_hi = lane + 64 < len && ((A_hi >> t) & 1) && (((M ^ R_hi) & A_hi & ~At) == 0);
-        const uint32_t vk = key(value);
+    // __adjust_heap(first, t, len, value) + its __push_heap, all levels at once.  At = ancestors of t.  TOP: t == 0.
+    template <bool TOP>
+    __device__ __forceinline__ void adjust(int t, u64 At, int len, NT value) {
+        bool on_lo, on_hi;
+        if constexpr (TOP) {
+            on_lo = lane < len && (((M ^ R_lo) & A_lo) == 0);
+            on_hi = lane + 64 < len && (((M ^ R_hi) & A_hi) == 0);
+        } else {
+            on_lo = lane < len && (lane == t || (((A_lo >> t) & 1) && (((M ^ R_lo) & A_lo & ~At) == 0)));
+            on_hi = lane + 64 < len && ((A_hi >> t) & 1) && (((M ^ R_hi) & A_hi & ~At) == 0);
+        }
         // __push_heap climbs from the bottom of the path while comp(parent, value): it stops at the deepest path
         // node (other than t) whose ORIGINAL value does not sort before `value`
-        const u64 c_lo = __ballot(on_lo && lane != t && !(key(lo) > vk));
-        const u64 c_hi = __ballot(on_hi && !(key(hi) > vk));
+        const u64 c_lo = __ballot(on_lo && lane != t && !N::gt(lo, value));
+        const u64 c_hi = __ballot(on_hi && !N::gt(hi, value));
         const int stop = c_hi ? 127 - __builtin_clzll(c_hi) : (c_lo ? 63 - __builtin_clzll(c_lo) : t);
-        const u64 child = ((M >> lane) & 1) ? xl : xr;                // the child the hole moved to
+        const NT child = ((M >> lane) & 1) ? xl : xr;                 // the child the hole moved to
         if (on_lo && lane <= stop) { lo = lane == stop ? value : child; arr[lane] = lo; }
         if (on_hi && lane + 64 == stop) { hi = value; arr[lane + 64] = hi; }
-        __syncthreads();
+        // one wave, and the LDS serves a wave's instructions in order: the reads below see the writes above without a
+        // barrier or a wait — only the compiler must keep them in this order
+        asm volatile("" ::: "memory");
         // refresh the children (and the "which child" bit) of the path's nodes and of t's parent
-        const bool refresh = on_lo || (t > 0 && lane == ((t - 1) >> 1));
+        const bool refresh = TOP ? on_lo : (on_lo || (t > 0 && lane == ((t - 1) >> 1)));
         if (refresh) { xl = arr[2 * lane + 1]; xr = arr[2 * lane + 2]; }
-        const u64 P = __ballot(refresh), B = __ballot(refresh && key(xr) > key(xl));
+        const u64 P = __ballot(refresh), B = __ballot(refresh && N::gt(xr, xl));
         M = (M & ~P) | B;
         set_len(len);
     }
 };
 
 // std::partial_sort(first, first + k, last, greater-by-value) for k <= 128, k >= 1; out[0..k) = indices.
-template <int DT>
-__device__ __forceinline__ void partial_sort_wave(const typename Dt<DT>::raw* s, int n, int k, u64* lds, int64_t* out) {
+template <int DT, class NT>
+__device__ __forceinline__ void partial_sort_wave(const typename Dt<DT>::raw* s, int n, int k, NT* lds, int64_t* out) {
+    typedef HeapNode<NT> N;
     const int lane = threadIdx.x;
-    WaveHeap H;
-    H.lo = lane < k ? (((u64)Key<DT>::of(s[lane]) << 32) | (uint32_t)lane) : 0;
-    H.hi = lane + 64 < k ? (((u64)Key<DT>::of(s[lane + 64]) << 32) | (uint32_t)(lane + 64)) : 0;
+    WaveHeap<NT> H;
+    H.lo = lane < k ? N::make(Key<DT>::of(s[lane]), lane) : 0;
+    H.hi = lane + 64 < k ? N::make(Key<DT>::of(s[lane + 64]), lane + 64) : 0;
     H.init(lds, k);
     // __make_heap
-    for (int t = (k - 2) / 2; t >= 0 && k >= 2; --t) H.adjust(t, WaveHeap::rdlane(H.A_lo, t), k, WaveHeap::rdlane(H.lo, t));
+    for (int t = (k - 2) / 2; t >= 0 && k >= 2; --t) {
+        const uint32_t a0 = __builtin_amdgcn_readlane((uint32_t)H.A_lo, t), a1 = __builtin_amdgcn_readlane((uint32_t)(H.A_lo >> 32), t);
+        H.template adjust<false>(t, ((u64)a1 << 32) | a0, k, N::rdlane(H.lo, t));
+    }
     // __heap_select: every later element that sorts before the root replaces it (__pop_heap + __adjust_heap)
-    uint32_t root = WaveHeap::key(WaveHeap::rdlane(H.lo, 0));
+    uint32_t root = N::key(N::rdlane(H.lo, 0));
     constexpr int U = 8;
     uint32_t cur[U], nxt[U];
 #pragma unroll
@@ -108,8 +138,8 @@ __device__ __forceinline__ void partial_sort_wave(const typename Dt<DT>::raw* s,
                 pending &= pending - 1;
                 const uint32_t kk = __builtin_amdgcn_readlane(cur[j], src);
                 if (kk > root) {                                       // re-test against the live root
-                    H.adjust(0, 0, k, ((u64)kk << 32) | (uint32_t)(i0 + src));
-                    root = WaveHeap::key(WaveHeap::rdlane(H.lo, 0));
+                    H.template adjust<true>(0, 0, k, N::make(kk, i0 + src));
+                    root = N::key(N::rdlane(H.lo, 0));
                 }
             }
         }
@@ -117,16 +147,16 @@ __device__ __forceinline__ void partial_sort_wave(const typename Dt<DT>::raw* s,
         for (int j = 0; j < U; ++j) cur[j] = nxt[j];
     }
     // __sort_heap: the root goes to a[last], a[last] is re-inserted from the top
-    u64* res = lds + 192;
+    NT* res = lds + 192;
     for (int last = k - 1; last >= 1; --last) {
-        const u64 value = H.node(last), top = WaveHeap::rdlane(H.lo, 0);
+        const NT value = H.node(last), top = N::rdlane(H.lo, 0);
         if (lane == 0) res[last] = top;
         H.set_len(last);
-        H.adjust(0, 0, last, value);
+        H.template adjust<true>(0, 0, last, value);
     }
     if (lane == 0) res[0] = H.lo;
     __syncthreads();
-    for (int t = lane; t < k; t += 64) out[t] = (int64_t)(res[t] & 0xffffffffull);
+    for (int t = lane; t < k; t += 64) out[t] = N::index(res[t]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -280,7 +310,8 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const SelectArgs a, u6
     const bool use_partial_sort = (int64_t)k * 64 <= (int64_t)n;
 
     if (use_partial_sort && k <= kWaveHeapMaxK) {
-        partial_sort_wave<DT>(s, n, k, lds_arr, out);
+        if constexpr (Key<DT>::bits == 16) partial_sort_wave<DT, uint32_t>(s, n, k, reinterpret_cast<uint32_t*>(lds_arr), out);   // n <= 65536
+        else partial_sort_wave<DT, u64>(s, n, k, lds_arr, out);
     } else if (use_partial_sort) {
         // heap of the first k in LDS; the tail is streamed 64 at a time
         Arr H{lds_arr};
