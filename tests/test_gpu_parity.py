@@ -346,3 +346,29 @@ def test_softmax_pool_forms_identical(kvc, gpu_device, name):
     b = kvc.scores(kvc.SNAPKV, qd, kd, m["W"], m["kernel"], m["pooling"], want_intermediates=True, softmax_path="fused")
     assert torch.equal(G.bits(a[0]), G.bits(b[0]))
     assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32)) and torch.equal(a[3].view(torch.int32), b[3].view(torch.int32))
+
+
+def _tie_heavy_scores(heads, n, dtype, seed, levels):
+    """Scores drawn from `levels` distinct values (plateaus like max-pooling makes), a few unique peaks on top."""
+    g = torch.Generator().manual_seed(seed)
+    vals = torch.rand(levels, generator=g).to(dtype)
+    sc = vals[torch.randint(0, levels, (heads, n), generator=g)]
+    peaks = torch.randint(0, n, (heads, 4), generator=g)
+    sc.scatter_(1, peaks, (torch.rand(heads, 4, generator=g) + 1.0).to(dtype))
+    return sc.contiguous()
+
+
+@pytest.mark.parametrize("n,k", [(300, 1), (300, 2), (300, 3), (300, 4), (8192, 64), (8192, 65), (8192, 127), (8192, 128),   # partial_sort, WaveHeap
+                                 (16384, 129), (16384, 256),                                                                 # partial_sort, k > 128 (scalar heap)
+                                 (300, 5), (300, 17), (300, 150), (300, 299), (300, 300), (1000, 16), (1000, 999),           # nth_element + sort
+                                 (18000, 282), (18001, 2000), (20000, 313), (40000, 5000)])                                  # array in LDS / in the workspace
+@pytest.mark.parametrize("dtype,levels", [(torch.bfloat16, 3), (torch.bfloat16, 40), (torch.float16, 500), (torch.float32, 7)])
+def test_exact_ties_random_plateaus_vs_oracle(kvc, oracle, gpu_device, n, k, dtype, levels):
+    """tie_mode torch_cpu on plateau-heavy random scores over the (n, k) corners of every code path — lane-parallel heap
+    (k <= 128, packed 32-bit nodes for 16-bit dtypes, 64-bit for fp32), scalar heap, lane-parallel partition with the
+    array in LDS or in the workspace, final placement — against the oracle, which runs the real std::partial_sort /
+    std::nth_element + std::sort.  Indices must be identical, order included."""
+    sc = _tie_heavy_scores(3, n, dtype, 1000 + n + k, levels)
+    want, _ = oracle.topk(sc, k, oracle.TIES_TORCH)
+    got = kvc.select(sc[None].to(gpu_device), k, "torch_cpu")[0].cpu()
+    assert torch.equal(got, want)
