@@ -159,6 +159,124 @@ __global__ __launch_bounds__(256) void h2o_rowsum_kernel(const H2OArgs a) {
 }
 
 // grid = (ceil(n / 256), bsz * n_q_heads), block = 256: one thread per key column.
+// ---- wide forms for 16-bit dtypes and L % 8 == 0 (the configuration sizes): same sums in the same order ----
+// Two elements of a packed 16-bit pair widened to fp32.
+template <int DT> __device__ __forceinline__ f32x2 widen2(uint32_t w) {
+    if constexpr (DT == KVC_BF16) return f32x2{u2f(w << 16), u2f(w & 0xffff0000u)};
+    else return f32x2{Dt<DT>::ld((uint16_t)(w & 0xffffu)), Dt<DT>::ld((uint16_t)(w >> 16))};
+}
+// h2o_rowsum_wide: two lanes per row, 32 rows per wave.  Lane `half` of a row owns the strided chains 8*half .. 8*half+7
+// (one 16-byte load per 16 elements), packed-fp32 exponentials; the xor-8 butterfly step is the one cross-lane add,
+// steps 4, 2, 1 fold the lane's own eight chains — the same tree as 16 lanes with one chain each.
+template <int DT>
+__global__ __launch_bounds__(256) void h2o_rowsum_wide_kernel(const H2OArgs a) {
+    typedef typename Dt<DT>::raw raw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hb = blockIdx.y, L = a.q_len;
+    const int r = (blockIdx.x * 4 + wave) * 32 + (lane >> 1);
+    const int half = lane & 1;
+    const bool valid = r < L;
+    const raw* row = reinterpret_cast<const raw*>(a.S) + ((int64_t)hb * L + (valid ? r : 0)) * L + 8 * half;
+    const float m = valid ? a.rowmax[(int64_t)hb * L + r] : 0.0f;
+    const f32x2 m2 = {m, m};
+    f32x2 acc[4];
+    {
+        const uint4 v = *reinterpret_cast<const uint4*>(row);
+        acc[0] = exp_u20x2(widen2<DT>(v.x) - m2); acc[1] = exp_u20x2(widen2<DT>(v.y) - m2);
+        acc[2] = exp_u20x2(widen2<DT>(v.z) - m2); acc[3] = exp_u20x2(widen2<DT>(v.w) - m2);
+    }
+    const int full = L - (L % 16);
+    int d = 16;
+    for (; d < full; d += 16) {
+        const uint4 v = *reinterpret_cast<const uint4*>(row + d);
+        acc[0] = acc[0] + exp_u20x2(widen2<DT>(v.x) - m2); acc[1] = acc[1] + exp_u20x2(widen2<DT>(v.y) - m2);
+        acc[2] = acc[2] + exp_u20x2(widen2<DT>(v.z) - m2); acc[3] = acc[3] + exp_u20x2(widen2<DT>(v.w) - m2);
+    }
+    if (8 * half < L - d) {                                // L % 16 == 8: the tail holds chains 0..7 only
+        const uint4 v = *reinterpret_cast<const uint4*>(row + d);
+        acc[0] = acc[0] + exp_u20x2(widen2<DT>(v.x) - m2); acc[1] = acc[1] + exp_u20x2(widen2<DT>(v.y) - m2);
+        acc[2] = acc[2] + exp_u20x2(widen2<DT>(v.z) - m2); acc[3] = acc[3] + exp_u20x2(widen2<DT>(v.w) - m2);
+    }
+    float t[8] = {acc[0].x, acc[0].y, acc[1].x, acc[1].y, acc[2].x, acc[2].y, acc[3].x, acc[3].y};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = t[e] + xor_lane<1>(t[e]);                  // chain c + chain c^8
+    const float u0 = t[0] + t[4], u1 = t[1] + t[5], u2 = t[2] + t[6], u3 = t[3] + t[7];   // ^4
+    const float v0 = u0 + u2, v1 = u1 + u3;                                                 // ^2
+    const float s = v0 + v1;                                                                // ^1
+    if (valid && half == 0) a.rinv[(int64_t)hb * L + r] = 1.0f / s;
+}
+// h2o_colsum_wide: one thread per PAIR of key columns (4-byte loads, packed-fp32 exp / scale / cascade adds).
+struct CascadeSum2 {
+    f32x2 a0, a1, a2, a3;
+    int i, in_step, level_step, level_power, full;
+    __device__ __forceinline__ void init(int size) {
+        int cl = 0;
+        while ((1 << cl) < size) ++cl;
+        level_power = cl / 4 > 4 ? cl / 4 : 4;
+        level_step = 1 << level_power;
+        full = size - (size % level_step);
+        a0 = a1 = a2 = a3 = f32x2{0.0f, 0.0f};
+        i = 0;
+        in_step = 0;
+    }
+    __device__ __forceinline__ void add(f32x2 v) {
+        a0 = a0 + v;
+        ++i;
+        ++in_step;
+        if (in_step == level_step && i <= full) {
+            in_step = 0;
+            const int mask = level_step - 1;
+            a1 = a1 + a0; a0 = f32x2{0.0f, 0.0f};
+            if ((i & (mask << level_power)) == 0) {
+                a2 = a2 + a1; a1 = f32x2{0.0f, 0.0f};
+                if ((i & (mask << (2 * level_power))) == 0) { a3 = a3 + a2; a2 = f32x2{0.0f, 0.0f}; }
+            }
+        }
+    }
+    __device__ __forceinline__ f32x2 result() const { return ((a0 + a1) + a2) + a3; }
+};
+template <int DT>
+__global__ __launch_bounds__(256) void h2o_colsum_wide_kernel(const H2OArgs a) {
+    const int hb = blockIdx.y, L = a.q_len, n = L - a.window;       // L and n even
+    const int jcol = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (jcol >= n) return;
+    const uint32_t* S = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.S) + ((int64_t)hb * L * L + jcol) * 2);
+    const float* m = a.rowmax + (int64_t)hb * L;
+    const float* ri = a.rinv + (int64_t)hb * L;
+    CascadeSum2 cs;
+    cs.init(L);
+    const int64_t pitch = L / 2;                                     // row pitch in 4-byte words
+    auto row = [&](uint32_t w, int r) {
+        const float mr = m[r], rr = ri[r];
+        const f32x2 e = exp_u20x2(widen2<DT>(w) - f32x2{mr, mr});
+        const f32x2 pr = e * f32x2{rr, rr};
+        cs.add(f32x2{rnd<DT>(pr.x), rnd<DT>(pr.y)});
+    };
+    // the rows are independent loads 2*L bytes apart: keep eight in flight while the previous eight are summed
+    constexpr int U = 8;
+    uint32_t cur[U], nxt[U];
+    int r = 0;
+    if (L >= U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = S[(int64_t)u * pitch];
+        for (; r + 2 * U <= L; r += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) nxt[u] = S[(int64_t)(r + U + u) * pitch];
+#pragma unroll
+            for (int u = 0; u < U; ++u) row(cur[u], r + u);
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) row(cur[u], r + u);
+        r += U;
+    }
+    for (; r < L; ++r) row(S[(int64_t)r * pitch], r);
+    const f32x2 res = cs.result();
+    reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.scores) + ((int64_t)hb * n + jcol) * 2)[0] =
+        (uint32_t)Dt<DT>::st(rnd<DT>(res.x)) | ((uint32_t)Dt<DT>::st(rnd<DT>(res.y)) << 16);
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void h2o_colsum_kernel(const H2OArgs a) {
     typedef typename Dt<DT>::raw raw;
@@ -186,8 +304,18 @@ static int launch_h2o_t(const H2OArgs& a, hipStream_t st) {
     const int L = a.q_len, n = L - a.window, heads = a.bsz * a.n_q_heads;
     const int row_tiles = (L + 31) / 32;
     hipLaunchKernelGGL((h2o_logits_kernel<DT, D>), dim3((unsigned)((row_tiles + 3) / 4), (unsigned)heads), dim3(256), lds, st, a);
-    hipLaunchKernelGGL((h2o_rowsum_kernel<DT>), dim3((unsigned)((L + 15) / 16), (unsigned)heads), dim3(256), 0, st, a);
-    hipLaunchKernelGGL((h2o_colsum_kernel<DT>), dim3((unsigned)((n + 255) / 256), (unsigned)heads), dim3(256), 0, st, a);
+    bool wide = false;
+    if constexpr (DT != KVC_FP32) wide = (L % 8) == 0 && (a.window % 2) == 0 && L >= 16;
+    if constexpr (DT != KVC_FP32) {
+        if (wide) {
+            hipLaunchKernelGGL((h2o_rowsum_wide_kernel<DT>), dim3((unsigned)((L + 127) / 128), (unsigned)heads), dim3(256), 0, st, a);
+            hipLaunchKernelGGL((h2o_colsum_wide_kernel<DT>), dim3((unsigned)((n / 2 + 255) / 256), (unsigned)heads), dim3(256), 0, st, a);
+        }
+    }
+    if (!wide) {
+        hipLaunchKernelGGL((h2o_rowsum_kernel<DT>), dim3((unsigned)((L + 15) / 16), (unsigned)heads), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((h2o_colsum_kernel<DT>), dim3((unsigned)((n + 255) / 256), (unsigned)heads), dim3(256), 0, st, a);
+    }
     return 0;
 }
 

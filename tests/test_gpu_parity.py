@@ -372,3 +372,15 @@ def test_exact_ties_random_plateaus_vs_oracle(kvc, oracle, gpu_device, n, k, dty
     want, _ = oracle.topk(sc, k, oracle.TIES_TORCH)
     got = kvc.select(sc[None].to(gpu_device), k, "torch_cpu")[0].cpu()
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("L,W", [(264, 8), (512, 32), (1000, 8), (300, 8)])
+def test_h2o_wide_softmax_forms_vs_oracle(kvc, oracle, gpu_device, L, W, dtype):
+    """H2O denominators and column sums have a wide form (two lanes per row with eight strided chains each; a pair of
+    key columns per thread; packed-fp32 exponentials) used when L % 8 == 0, and the one-element form otherwise (L = 300).
+    Both must equal the oracle bit for bit — L % 16 == 8 (264, 1000) exercises the half-empty last stride."""
+    q, k, v = G.synth.make_qkv(8, 2, L, 128, dtype, 900 + L)
+    sc_o = oracle.scores(q, k, W, 7, "avgpool", full_rows=True, dot_mode=oracle.DOT_CHAIN, sum_mode=oracle.SUM_TORCH16)
+    sc_g = kvc.scores(kvc.H2O, q.to(gpu_device), k.to(gpu_device), W, 7, None)
+    assert torch.equal(G.bits(sc_g[0]), G.bits(sc_o))                       # tolerance: 0 ulp
