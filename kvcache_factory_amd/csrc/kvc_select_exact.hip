@@ -318,20 +318,31 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const SelectArgs a, u6
         for (int i = lane; i < k; i += 64) lds_arr[i] = ((u64)Key<DT>::of(s[i]) << 32) | (uint32_t)i;
         __syncthreads();
         make_heap_(H, 0, k);
-        for (int base = k; base < n; base += 64) {
-            const int i = base + lane;
-            const uint32_t key = i < n ? Key<DT>::of(s[i]) : 0u;
-            u64 root = H.get(0);
-            unsigned long long pending = __ballot(i < n && key > (uint32_t)(root >> 32));
-            while (pending) {
-                const int src = __builtin_ctzll(pending);
-                pending &= pending - 1;
-                const uint32_t kk = __builtin_amdgcn_readlane(key, src);
-                if (kk > (uint32_t)(root >> 32)) {                       // re-test against the live root
-                    adjust_heap_(H, 0, 0, k, ((u64)kk << 32) | (uint32_t)(base + src));
-                    root = H.get(0);
+        // the tail is read eight 64-key chunks ahead (a chunk fetched on demand costs a full memory round trip per 64 keys)
+        constexpr int U = 8;
+        uint32_t cur[U], nxt[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) { const int i = k + j * 64 + lane; cur[j] = i < n ? Key<DT>::of(s[i]) : 0u; }
+        u64 root = H.get(0);
+        for (int base = k; base < n; base += U * 64) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) { const int i = base + (U + j) * 64 + lane; nxt[j] = i < n ? Key<DT>::of(s[i]) : 0u; }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int i0 = base + j * 64;
+                unsigned long long pending = __ballot(i0 + lane < n && cur[j] > (uint32_t)(root >> 32));
+                while (pending) {
+                    const int src = __builtin_ctzll(pending);
+                    pending &= pending - 1;
+                    const uint32_t kk = __builtin_amdgcn_readlane(cur[j], src);
+                    if (kk > (uint32_t)(root >> 32)) {                   // re-test against the live root
+                        adjust_heap_(H, 0, 0, k, ((u64)kk << 32) | (uint32_t)(i0 + src));
+                        root = H.get(0);
+                    }
                 }
             }
+#pragma unroll
+            for (int j = 0; j < U; ++j) cur[j] = nxt[j];
         }
         sort_heap_(H, 0, k);
         __syncthreads();
