@@ -384,3 +384,18 @@ def test_h2o_wide_softmax_forms_vs_oracle(kvc, oracle, gpu_device, L, W, dtype):
     sc_o = oracle.scores(q, k, W, 7, "avgpool", full_rows=True, dot_mode=oracle.DOT_CHAIN, sum_mode=oracle.SUM_TORCH16)
     sc_g = kvc.scores(kvc.H2O, q.to(gpu_device), k.to(gpu_device), W, 7, None)
     assert torch.equal(G.bits(sc_g[0]), G.bits(sc_o))                       # tolerance: 0 ulp
+
+
+@pytest.mark.parametrize("L,keeps", [(8200, [1, 100, 128, 129, 500, 4000]),        # n = 8192: WaveHeap | nth_element (array in LDS)
+                                     (20008, [7, 128, 200, 312, 313, 5000])])      # n = 20000: WaveHeap | scalar heap | nth_element in the workspace
+def test_batch_mixing_exact_tie_regimes(kvc, gpu_device, L, keeps):
+    """One kvc_compress_batch launch whose items fall into different libstdc++ regimes (partial_sort with the
+    lane-parallel heap, partial_sort with the scalar heap, nth_element + sort with the array in LDS or in the
+    workspace): LDS and scratch are sized for the worst item; every item equals its own kvc_compress call."""
+    W = 8
+    qkv = [G.synth.make_qkv(32, 8, L, 128, torch.bfloat16, 700 + i, device=gpu_device) for i in range(len(keeps))]
+    bp = kvc.BatchPlan(kvc.SNAPKV, qkv, W, keeps, 7, "maxpool", "torch_cpu", want_indices=True)
+    ko, vo = bp.run()
+    for i, (q, k, v) in enumerate(qkv):
+        k1, v1, i1 = kvc.compress(kvc.SNAPKV, q, k, v, W, keeps[i], 7, "maxpool", "torch_cpu", return_indices=True)
+        assert torch.equal(bp.idx[i], i1) and torch.equal(ko[i], k1) and torch.equal(vo[i], v1)
