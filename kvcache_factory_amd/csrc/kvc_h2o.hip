@@ -34,19 +34,39 @@ template <> __device__ __forceinline__ float pick2<KVC_FP32>(const uint4& v, int
     return u2f(w);
 }
 
+// x / sqrt(D), bit-identical to the IEEE division (same construction and guard as ScaleDiv in kvc_score.hip:
+// tests/test_fastdiv.py checks all 2^32 inputs of the D = 128 form).
+template <int D> __device__ __forceinline__ float h2o_scale(float x, float c) {
+    if constexpr (D == 64) {
+        return x * 0.125f;
+    } else {
+        const float rc = u2f(0x3db504f3u);                         // RN(1 / sqrt(128))
+        const float ax = __builtin_fabsf(x);
+        if (__builtin_expect(!(ax >= u2f(0x0d800000u) && ax < __builtin_inff()), 0)) return x / c;
+        const float q0 = x * rc;
+        const float r = __builtin_fmaf(-q0, c, x);
+        return __builtin_fmaf(r, rc, q0);
+    }
+}
+
 // grid = (ceil(row_tiles / 4), bsz * n_q_heads), block = 256: wave w of block x owns query rows [32*(4x+w), +32).
 template <int DT, int D>
 __global__ __launch_bounds__(256) void h2o_logits_kernel(const H2OArgs a) {
     typedef typename Dt<DT>::raw raw;
     constexpr int ES = Dt<DT>::esize;
     constexpr int ROWB = D * ES, CH = ROWB / 16, PAIRS = 8 / ES, SWZ = CH < 16 ? CH - 1 : 15, STG = CH / 2;
+    // (Operands widened by ds_read_u16_d16_hi as in kvc_score.hip were tried here and REJECTED: with this kernel's
+    // double-buffered tiles the hand-issued loads produced rare, run-to-run different 1-ulp logit errors at L = 8000
+    // (about one logit in 10^6; cause not found).  The B operand keeps its v_perm widening.)
+    constexpr bool ASM_B = false;
+    constexpr int ROWP = ROWB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
     const int hb = blockIdx.y, b = hb / a.n_q_heads, h = hb % a.n_q_heads, g = h / a.group;
     const int L = a.q_len, W = a.window;
     const int r0 = (blockIdx.x * 4 + wave) * 32;
     if (r0 >= L) return;                                   // whole wave idle (no barriers below)
-    char* const buf = smem + wave * (2 * 32 * ROWB);
+    char* const buf = smem + wave * (2 * 32 * ROWP);
     const int n_t = (L + 31) / 32;
     const float sqrt_d = a.sqrt_d;
     const char* kbase = reinterpret_cast<const char*>(a.k) + ((int64_t)b * a.k_stride_b + (int64_t)g * a.k_stride_h) * ES;
@@ -63,7 +83,12 @@ __global__ __launch_bounds__(256) void h2o_logits_kernel(const H2OArgs a) {
 #pragma unroll
         for (int it = 0; it < STG; ++it) {
             const int c = it * 64 + lane, r = c / CH, cc = c % CH;
-            *reinterpret_cast<uint4*>(dst + r * ROWB + ((cc ^ (r & SWZ)) * 16)) = st[it];
+            if constexpr (ASM_B) {
+                uint32_t* d = reinterpret_cast<uint32_t*>(dst + r * ROWP + cc * 16);
+                d[0] = st[it].x; d[1] = st[it].y; d[2] = st[it].z; d[3] = st[it].w;
+            } else {
+                *reinterpret_cast<uint4*>(dst + r * ROWB + ((cc ^ (r & SWZ)) * 16)) = st[it];
+            }
         }
     };
 
@@ -91,22 +116,24 @@ __global__ __launch_bounds__(256) void h2o_logits_kernel(const H2OArgs a) {
     for (int tile = 0; tile < n_t; ++tile) {
         if (tile + 1 < n_t) issue(tile + 1, st);
         __builtin_amdgcn_wave_barrier();
-        const char* krow = buf + cur * (32 * ROWB) + j * ROWB;
+        const char* krow = buf + cur * (32 * ROWP) + j * ROWP;
         const int key = tile * 32 + j;
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        {
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const uint4 kv = *reinterpret_cast<const uint4*>(krow + ((c ^ (j & SWZ)) * 16));
+            for (int c = 0; c < CH; ++c) {
+                const uint4 kv = *reinterpret_cast<const uint4*>(krow + ((c ^ (j & SWZ)) * 16));
 #pragma unroll
-            for (int s = 0; s < PAIRS; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c * PAIRS + s], pick2<DT>(kv, s, kh), acc, 0, 0, 0);
+                for (int s = 0; s < PAIRS; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c * PAIRS + s], pick2<DT>(kv, s, kh), acc, 0, 0, 0);
+            }
         }
         const bool tailk = tile * 32 + 32 > L - W, tailr = r0 + 32 > L - W;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int r = r0 + (e & 3) + 8 * (e >> 2) + 4 * kh;
             float v = rnd<DT>(acc[e]);
-            v = rnd<DT>(v / sqrt_d);
+            v = rnd<DT>(h2o_scale<D>(v, sqrt_d));
             if (tailk && tailr) {
                 if (r >= L - W && key >= L - W && (key - (L - W)) > (r - (L - W))) v = rnd<DT>(v + Dt<DT>::finfo_min());
             }
@@ -115,7 +142,7 @@ __global__ __launch_bounds__(256) void h2o_logits_kernel(const H2OArgs a) {
                 rmax[e] = v > rmax[e] ? v : rmax[e];
             }
         }
-        if (tile + 1 < n_t) commit(buf + (cur ^ 1) * (32 * ROWB), st);
+        if (tile + 1 < n_t) commit(buf + (cur ^ 1) * (32 * ROWP), st);
         cur ^= 1;
     }
     // exact row maxima: reduce each register over the 32 key lanes of its half-wave

@@ -399,3 +399,25 @@ def test_batch_mixing_exact_tie_regimes(kvc, gpu_device, L, keeps):
     for i, (q, k, v) in enumerate(qkv):
         k1, v1, i1 = kvc.compress(kvc.SNAPKV, q, k, v, W, keeps[i], 7, "maxpool", "torch_cpu", return_indices=True)
         assert torch.equal(bp.idx[i], i1) and torch.equal(ko[i], k1) and torch.equal(vo[i], v1)
+
+
+def test_kscan_batch_vs_call_stress(kvc, gpu_device):
+    """The exact bf16 K scan issues its LDS operand reads by hand (ds_read_u16_d16_hi + explicit s_waitcnt, kvc_score.hip).
+    A rare operand hazard would show as run-to-run different bits, so: the pooled scores of a 32-layer batch launch (21
+    tiles per wave) must equal the per-call path (one tile per wave) on all 8.2 M scores, three launches in a row.
+    (tools/stress_logits.py runs the longer version, 1 G logits, and checks layer 0 against the oracle.)"""
+    import ctypes
+    L, W, layers = 8000, 8, 32
+    qkv = [G.synth.make_qkv(32, 8, L, 128, torch.bfloat16, 10 + l, device=gpu_device) for l in range(layers)]
+    ref = [kvc.scores(kvc.SNAPKV, q, k, W, 7, "maxpool")[0].clone() for q, k, v in qkv]
+    bp = kvc.BatchPlan(kvc.SNAPKV, qkv, W, 120, 7, "maxpool", "canonical", want_indices=True)
+    sc = [torch.empty(32, L - W, dtype=torch.bfloat16, device=gpu_device) for _ in range(layers)]
+    arr = (ctypes.c_void_p * layers)(*[t.data_ptr() for t in sc])
+    for rep in range(3):
+        for t in sc:
+            t.zero_()
+        rc = kvc.lib().kvc_compress_batch(ctypes.byref(bp.p), bp.n, bp._keep, bp._q, bp._k, bp._v, bp._ko, bp._vo, bp._ix, arr,
+                                          kvc._ptr(bp.ws), bp.nbytes, kvc._stream(gpu_device))
+        assert rc == 0, kvc.lib().kvc_last_error()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a.view(torch.int16), b.view(torch.int16)) for a, b in zip(sc, ref))
