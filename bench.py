@@ -299,7 +299,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--tie-mode", default="canonical", choices=["canonical", "torch_cpu"])
+    ap.add_argument("--tie-mode", default="torch_cpu", choices=["canonical", "torch_cpu"],
+                    help="torch_cpu (default, the clusters' default): indices bit-identical to the reference's CPU run, "
+                         "ties included; canonical: value desc / index asc, faster, differs only inside tie groups")
     ap.add_argument("--mode", default="batch", choices=["batch", "calls"],
                     help="batch: one kvc_compress_batch call per step (all 32 layers per kernel launch); "
                          "calls: 32 kvc_compress calls per step spread over --streams streams")
