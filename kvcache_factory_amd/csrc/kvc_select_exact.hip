@@ -29,6 +29,18 @@ namespace kvc {
 // ---------------------------------------------------------------------------------------------------------
 // Node word: (key << 32 | index) in 64 bits, or — 16-bit dtypes, n <= 65536 — (key << 16 | index) in 32 bits, which
 // halves every move, compare and LDS access of the heap.
+// Lane-wise select by a wave mask held in SGPRs: bit l of `mask` set -> b, else a.  One v_cndmask per dword, no
+// VGPR boolean in between (the compiler's own lowering of `mask-bit ? b : a` goes through v_lshrrev_b64 / v_cmp).
+__device__ __forceinline__ uint32_t lane_sel(uint32_t a, uint32_t b, u64 mask) {
+    uint32_t d;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(mask));
+    return d;
+}
+__device__ __forceinline__ u64 lane_sel(u64 a, u64 b, u64 mask) {
+    const uint32_t lo = lane_sel((uint32_t)a, (uint32_t)b, mask), hi = lane_sel((uint32_t)(a >> 32), (uint32_t)(b >> 32), mask);
+    return ((u64)hi << 32) | lo;
+}
+
 template <class NT> struct HeapNode;
 template <> struct HeapNode<u64> {
     __device__ __forceinline__ static u64 make(uint32_t key, int idx) { return ((u64)key << 32) | (uint32_t)idx; }
@@ -74,6 +86,30 @@ struct WaveHeap {
     }
     __device__ __forceinline__ void set_len(int len) {               // a node with only a left child moves left
         if (len >= 2 && (len & 1) == 0) M |= 1ull << ((len - 2) >> 1);
+    }
+    // The same step for t == 0 (every replacement of the tail scan, every pop of __sort_heap), written on wave masks:
+    // predicates are ballots combined on the scalar unit, values move through mask-driven v_cndmask, every lane writes
+    // its node(s) and re-reads its children unconditionally — no branch, no EXEC change, ~40 instructions.
+    // in_lo / in_hi: lanes whose node index is below len.
+    __device__ __forceinline__ void adjust_top(u64 in_lo, u64 in_hi, int len, NT value) {
+        const u64 on_lo = __ballot(((M ^ R_lo) & A_lo) == 0) & in_lo;        // lane 0 has no ancestors: always on
+        const u64 on_hi = __ballot(((M ^ R_hi) & A_hi) == 0) & in_hi;
+        const u64 c_lo = on_lo & ~__ballot(N::gt(lo, value)) & ~1ull;        // push-up stops: path nodes not sorting before value
+        const u64 c_hi = on_hi & ~__ballot(N::gt(hi, value));
+        const int stop = c_hi ? 127 - __builtin_clzll(c_hi) : (c_lo ? 63 - __builtin_clzll(c_lo) : 0);
+        const u64 below = stop >= 64 ? ~0ull : ((1ull << stop) - 1);
+        const u64 eq_lo = stop >= 64 ? 0ull : (1ull << stop), eq_hi = stop >= 64 ? (1ull << (stop - 64)) : 0ull;
+        const NT child = lane_sel(xr, xl, M);                               // the child the hole moved to (bit set: left)
+        NT vv = value;
+        asm volatile("" : "+v"(vv));                                          // the value in a VGPR, once
+        lo = lane_sel(lane_sel(lo, child, on_lo & below), vv, eq_lo);
+        hi = lane_sel(hi, vv, eq_hi);
+        arr[lane] = lo;
+        arr[lane + 64] = hi;
+        asm volatile("" ::: "memory");                                        // one wave, LDS in order
+        xl = arr[2 * lane + 1]; xr = arr[2 * lane + 2];
+        M = __ballot(N::gt(xr, xl));                                          // every node's bit anew; unused ones are ignored
+        set_len(len);
     }
     // __adjust_heap(first, t, len, value) + its __push_heap, all levels at once.  At = ancestors of t.  TOP: t == 0.
     template <bool TOP>
@@ -122,6 +158,7 @@ __device__ __forceinline__ void partial_sort_wave(const typename Dt<DT>::raw* s,
     }
     // __heap_select: every later element that sorts before the root replaces it (__pop_heap + __adjust_heap)
     uint32_t root = N::key(N::rdlane(H.lo, 0));
+    u64 in_lo = k >= 64 ? ~0ull : ((1ull << k) - 1), in_hi = k > 64 ? ((k >= 128 ? 0ull : (1ull << (k - 64))) - 1) : 0ull;
     constexpr int U = 8;
     uint32_t cur[U], nxt[U];
 #pragma unroll
@@ -138,7 +175,7 @@ __device__ __forceinline__ void partial_sort_wave(const typename Dt<DT>::raw* s,
                 pending &= pending - 1;
                 const uint32_t kk = __builtin_amdgcn_readlane(cur[j], src);
                 if (kk > root) {                                       // re-test against the live root
-                    H.template adjust<true>(0, 0, k, N::make(kk, i0 + src));
+                    H.adjust_top(in_lo, in_hi, k, N::make(kk, i0 + src));
                     root = N::key(N::rdlane(H.lo, 0));
                 }
             }
@@ -152,7 +189,9 @@ __device__ __forceinline__ void partial_sort_wave(const typename Dt<DT>::raw* s,
         const NT value = H.node(last), top = N::rdlane(H.lo, 0);
         if (lane == 0) res[last] = top;
         H.set_len(last);
-        H.template adjust<true>(0, 0, last, value);
+        in_lo = last >= 64 ? ~0ull : ((1ull << last) - 1);
+        in_hi = last > 64 ? ((1ull << (last - 64)) - 1) : 0ull;
+        H.adjust_top(in_lo, in_hi, last, value);
     }
     if (lane == 0) res[0] = H.lo;
     __syncthreads();
