@@ -4,17 +4,17 @@
 //   sum over the W window rows                    :327
 //   1-D max / avg pooling                         :328-333
 //
-// Three kernels, one HBM pass over K:
-//   logits_kernel  : one workgroup = 128 keys of one KV head; the K tile is staged once in LDS
-//                    (coalesced 16-B loads, XOR-swizzled rows) and contracted against the G*W query
-//                    rows of the KV head's query group with the f32-input MFMA
-//                    v_mfma_f32_32x32x2_f32, whose result is bit for bit the d-ascending fmaf chain
-//                    the oracle computes (KVCO_DOT_CHAIN).  Epilogue applies the reference's three
-//                    roundings, writes logits [h][L][W] and the tile's per-row maximum.
-//   rowsum_kernel  : one workgroup = 256 keys of one query head: row max from the tile maxima,
-//                    e = exp_u20(x - max), fixed-order partial sums (oracle: sum_kvc).
-//   pool_kernel    : one workgroup = 256 candidate keys (+ pooling halo): p = round(e / sum),
-//                    window sum in torch's cascade order, round, pool, write the scores.
+// One HBM pass over K, then the softmax / window-sum / pooling stage in one of two forms:
+//   logits_kernel        : 4 autonomous waves per workgroup, each walking 32-key tiles of one KV head: K tile ->
+//                          registers -> padded LDS rows, contracted against the G*W query rows of the head's query
+//                          group with v_mfma_f32_32x32x2_f32, whose result is bit for bit the d-ascending fmaf
+//                          chain the oracle computes (KVCO_DOT_CHAIN); dot_mode mfma16 uses the packed 16-bit MFMA
+//                          instead (tolerance mode).  Epilogue: the reference's three roundings, logits
+//                          [h][L][W] and per-workgroup row maxima.  Design notes at the kernel.
+//   softmax_pool_kernel  : one 1024-thread workgroup per head (batched launches): exponentials, fixed-order row
+//                          sums (oracle: sum_kvc), p = round(e / sum), window sum in torch's cascade order, round,
+//                          pool, write the scores.
+//   rowsum_kernel + pool_kernel : the same arithmetic split over many workgroups per head (per-layer calls).
 #include <type_traits>
 
 #include "kvc_common.h"
@@ -74,14 +74,7 @@ template <> __device__ __forceinline__ float pick<KVC_FP32>(const uint4& v, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// logits_kernel
-// grid  = (blocks per KV head, bsz * n_kv_heads), block = 256 = 4 autonomous waves.
-// Each wave owns 32-key tiles  t = wave_id, wave_id + n_waves, ...  of its KV head: it stages the tile in its OWN
-// double-buffered LDS region (coalesced 16-B global loads -> registers -> XOR-swizzled ds_write), so there is no
-// workgroup barrier in the loop and the loads of tile t+1 fly while tile t is contracted:
-//   64 x v_mfma_f32_32x32x2_f32 per tile (the exact d-ascending fmaf chain), then the epilogue (3 roundings,
-//   mask), 8-byte packed stores of logits [h][key][w] and a running per-row maximum.
-// LDS   = 4 waves * 2 buffers * 32 keys * D * esize (+ 4*32 floats for the final cross-wave maximum)
+// x / sqrt(D) as the reference computes it
 // ---------------------------------------------------------------------------------------------
 template <int D> struct ScaleDiv;            // x / sqrt(D) in fp32, bit-identical to the IEEE division
 template <> struct ScaleDiv<64> {            // sqrt(64) = 8: multiplying by 2^-3 IS the division (exact scaling)
