@@ -170,7 +170,6 @@ int enqueue_scores(const kvc_params* p, const Layout& l, const Items& it, char* 
     a.n_tiles = l.n_tiles; a.n_chunks = l.n_chunks;
     a.kernel_size = p->kernel_size; a.pooling = p->pooling;
     a.stage_mask = p->debug_stage_mask;
-    a.nbuf = 1;
     a.fast_dot = (p->dot_mode == KVC_DOT_MFMA16 && p->dtype != KVC_FP32) ? 1 : 0;
     a.dbg = nullptr;
 #if defined(KVC_STAMPS)

@@ -33,7 +33,6 @@ struct ScoreArgs {
     int bsz, n_q_heads, n_kv_heads, group, q_len, window;
     int n_tiles, n_chunks, kernel_size, pooling;
     int fast_dot;          // 1: packed bf16/fp16 MFMA scan (tolerance mode), 0: exact f32 fmaf-chain MFMA
-    int nbuf;              // K-tile buffers per wave in logits_kernel: 1 if every wave owns a single tile, else 2
     int stage_mask;        // bits 0-2: 0 = all, else bit0 logits, bit1 rowsum, bit2 pool (profiling aid); bit3 / bit4: force the split / fused softmax path
     float sqrt_d;
     unsigned long long* dbg;   // diagnostic stamps (KVC_STAMPS builds only), else null

@@ -11,10 +11,13 @@
 //    the sift-down path is known from a 64-bit mask of "which child wins" bits, so every node decides by itself
 //    whether it is on the path, the push-up stop is a ballot, and only the path's bits are refreshed afterwards.
 //    Same moves, same final array as the serial routine (kvc_stl_emul.h), ~4x fewer dependent steps.
-//  * everything else: the scalar program of kvc_stl_emul.h, every lane running the same code on wave-uniform values,
-//    array in LDS when it fits (n <= 18000 elements of 8 bytes) and in the caller's workspace otherwise.
+//  * nth_element + sort (k*64 > n): WaveSel below — lane-parallel __unguarded_partition and final insertion
+//    placement, array in LDS when it fits (n <= 18000 elements of 8 bytes) and in the caller's workspace otherwise.
+//  * partial_sort with k > 128 and the depth-limit fallbacks: the scalar program of kvc_stl_emul.h, every lane
+//    running the same code on wave-uniform values.
 //
-// This is the exact path (serial by construction); the canonical path is kvc_select.hip.
+// One wave per head: the run time is the latency of that head's chain of moves, not a throughput; the canonical
+// path (kvc_select.hip) is the fast one.
 #include "kvc_common.h"
 #include "kvc_launch.h"
 #include "kvc_stl_emul.h"
