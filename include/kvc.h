@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KVC_VERSION 1
+#define KVC_VERSION 2
 
 typedef enum kvc_status {
     KVC_OK = 0,
@@ -92,6 +92,11 @@ typedef struct kvc_params {
     int64_t q_stride_b, q_stride_h, q_stride_l;   /* element strides of q[b][h][l][:] */
     int64_t k_stride_b, k_stride_h, k_stride_l;
     int64_t v_stride_b, v_stride_h, v_stride_l;
+    int64_t out_stride_h;      /* elements between consecutive heads of k_out / v_out ([b][h_q][row][D], rows dense).
+                                  0 = dense, (k + window) * head_dim.  Larger: the caller's decode cache with spare rows
+                                  per head ([b][h_q][capacity][D]) — K' / V' are written straight into their final home
+                                  (the reference cats them into a fresh tensor, llama_model.py:286).  A multiple of 8
+                                  (16-bit) or 4 (fp32) elements, >= (largest k + window) * head_dim. */
 } kvc_params;
 
 /* Library / ABI version (== KVC_VERSION). */

@@ -37,7 +37,7 @@ class Params(ctypes.Structure):
         "kernel_size", "pooling", "tie_mode", "debug_stage_mask", "dot_mode")] + [
         (n, ctypes.c_int64) for n in (
             "q_stride_b", "q_stride_h", "q_stride_l", "k_stride_b", "k_stride_h", "k_stride_l",
-            "v_stride_b", "v_stride_h", "v_stride_l")]
+            "v_stride_b", "v_stride_h", "v_stride_l", "out_stride_h")]
 
 
 _lib = None
@@ -134,9 +134,26 @@ def _require_gpu(*ts):
                                "there is no CPU fallback" % t.device.type)
 
 
+def _out_views(out, bsz, hq, rows, D, dtype, dev):
+    """Caller-provided output buffers [bsz, H_q, capacity >= rows, D] (e.g. a decode cache with spare rows per head):
+    returns (k_buf, v_buf, head stride in elements); None -> fresh dense tensors, stride 0 (= dense)."""
+    if out is None:
+        k_out = torch.empty(bsz, hq, rows, D, dtype=dtype, device=dev)
+        return k_out, torch.empty_like(k_out), 0
+    kb, vb = out
+    for t in (kb, vb):
+        assert t.dim() == 4 and t.shape[0] == bsz and t.shape[1] == hq and t.shape[2] >= rows and t.shape[3] == D and \
+            t.dtype == dtype and t.device == dev and t.stride(3) == 1 and t.stride(2) == D and \
+            t.stride(0) == hq * t.stride(1), "out buffers must be [bsz, H_q, capacity, D] with dense rows"
+    assert kb.stride(1) == vb.stride(1)
+    return kb, vb, kb.stride(1)
+
+
 def compress(method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu",
-             n_q_heads=None, return_indices=False, return_scores=False, dot_mode=None):
-    """One update_kv body on the GPU: returns (k_out, v_out[, idx][, scores])."""
+             n_q_heads=None, return_indices=False, return_scores=False, dot_mode=None, out=None):
+    """One update_kv body on the GPU: returns (k_out, v_out[, idx][, scores]).
+    out=(k_buf, v_buf): write K' / V' into the first k + window rows of each head of these [bsz, H_q, capacity, D]
+    buffers (kvc_params.out_stride_h) and return views of them."""
     _require_gpu(q, k, v)
     k, v = _last_dim_contig(k), _last_dim_contig(v)
     if q is not None:
@@ -151,8 +168,7 @@ def compress(method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", 
         p = make_params(method, q, k, v, window, n_keep, kernel_size, pooling, tie_mode, dot_mode)
         hq, qq = q.shape[1], q
     bsz, L, D = k.shape[0], k.shape[2], k.shape[3]
-    k_out = torch.empty(bsz, hq, n_keep + window, D, dtype=k.dtype, device=dev)
-    v_out = torch.empty_like(k_out)
+    k_out, v_out, p.out_stride_h = _out_views(out, bsz, hq, n_keep + window, D, k.dtype, dev)
     scoring = method != STREAMINGLLM
     idx = torch.empty(bsz, hq, n_keep, dtype=torch.int64, device=dev) if (return_indices and scoring) else None
     sc = torch.empty(bsz, hq, L - window, dtype=k.dtype, device=dev) if (return_scores and scoring) else None
@@ -162,7 +178,7 @@ def compress(method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", 
     ws = workspace(dev, nbytes) if nbytes else None
     _check(lib().kvc_compress(ctypes.byref(p), _ptr(qq), _ptr(k), _ptr(v), _ptr(k_out), _ptr(v_out), _ptr(idx),
                               _ptr(sc), _ptr(ws), nbytes, _stream(dev)))
-    out = [k_out, v_out]
+    out = [k_out[:, :, :n_keep + window], v_out[:, :, :n_keep + window]]
     if return_indices:
         if not scoring:
             idx = torch.arange(n_keep, device=dev).expand(bsz, hq, n_keep).contiguous()
@@ -286,7 +302,7 @@ class BatchPlan:
     q may be None for StreamingLLM (n_q_heads then names the output heads)."""
 
     def __init__(self, method, qkv, window, n_keep, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu",
-                 want_indices=False, dot_mode=None, q_rows="all", n_q_heads=None):
+                 want_indices=False, dot_mode=None, q_rows="all", n_q_heads=None, outs=None):
         n = len(qkv)
         q0, k0, v0 = qkv[0]
         _require_gpu(q0, k0, v0)
@@ -312,16 +328,25 @@ class BatchPlan:
             assert q_rows == "all" and (not scoring or q.shape[2] == k.shape[2])
         dev = k.device
         bsz, hq, D = k.shape[0], self.p.n_q_heads, k.shape[3]
-        self.k_out = [torch.empty(bsz, hq, kk + window, D, dtype=k.dtype, device=dev) for kk in keeps]
-        self.v_out = [torch.empty_like(t) for t in self.k_out]
+        if outs is None:
+            self.k_out = [torch.empty(bsz, hq, kk + window, D, dtype=k.dtype, device=dev) for kk in keeps]
+            self.v_out = [torch.empty_like(t) for t in self.k_out]
+            kbufs, vbufs = self.k_out, self.v_out
+        else:                                              # caller's buffers, one (k_buf, v_buf) per item, one head stride
+            trip = [_out_views(o, bsz, hq, kk + window, D, k.dtype, dev) for o, kk in zip(outs, keeps)]
+            assert len({t[2] for t in trip}) == 1, "out buffers must share one head stride"
+            self.p.out_stride_h = trip[0][2]
+            kbufs, vbufs = [t[0] for t in trip], [t[1] for t in trip]
+            self.k_out = [t[0][:, :, :kk + window] for t, kk in zip(trip, keeps)]
+            self.v_out = [t[1][:, :, :kk + window] for t, kk in zip(trip, keeps)]
         self.idx = [torch.empty(bsz, hq, kk, dtype=torch.int64, device=dev) for kk in keeps] if (want_indices and scoring) else None
         arr = ctypes.c_void_p * n
         self._keep = (ctypes.c_int32 * n)(*keeps)
         self._q = arr(*[t[0].data_ptr() - q_off for t in self.items]) if scoring else None
         self._k = arr(*[t[1].data_ptr() for t in self.items])
         self._v = arr(*[t[2].data_ptr() for t in self.items])
-        self._ko = arr(*[t.data_ptr() for t in self.k_out])
-        self._vo = arr(*[t.data_ptr() for t in self.v_out])
+        self._ko = arr(*[t.data_ptr() for t in kbufs])
+        self._vo = arr(*[t.data_ptr() for t in vbufs])
         self._ix = arr(*[t.data_ptr() for t in self.idx]) if self.idx is not None else None
         self.nbytes = lib().kvc_workspace_bytes_batch(ctypes.byref(self.p), n, self._keep)
         if self.nbytes == 0 and scoring:
@@ -339,11 +364,11 @@ class BatchPlan:
 
 
 def compress_batch(method, qs, ks, vs, window, keeps, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu",
-                   q_rows="all", n_q_heads=None, return_indices=False, dot_mode=None):
+                   q_rows="all", n_q_heads=None, return_indices=False, dot_mode=None, outs=None):
     """n independent update_kv bodies of one layout in ONE library call (kvc_compress_batch): lists of k_out, v_out
     (and indices).  See BatchPlan for q_rows."""
     qs = qs if qs is not None else [None] * len(ks)
     bp = BatchPlan(method, list(zip(qs, ks, vs)), window, keeps, kernel_size, pooling, tie_mode, return_indices,
-                   dot_mode, q_rows, n_q_heads)
+                   dot_mode, q_rows, n_q_heads, outs)
     bp.run()
     return (bp.k_out, bp.v_out, bp.idx) if return_indices else (bp.k_out, bp.v_out)

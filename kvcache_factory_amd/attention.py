@@ -91,7 +91,8 @@ def make_forward(method, apply_rotary_pos_emb, eager_attention_forward, repeat_k
                 q_len = key_states.shape[-2]
                 taken = pu.BATCH_LAYERS and pending.add(
                     self.kv_cluster, key_states, query_states, value_states,
-                    lambda kc, vc, layer=layer, q_len=q_len: layer.prefill(kc, vc, q_len), tag=layer)
+                    lambda kc, vc, layer=layer, q_len=q_len: layer.prefill(kc, vc, q_len), tag=layer,
+                    alloc=layer.reserve)                                     # K' / V' land in the decode cache itself
                 if not taken:
                     kc, vc = self.kv_cluster.update_kv(key_states, query_states, value_states, attention_mask,
                                                        self.num_key_value_groups)

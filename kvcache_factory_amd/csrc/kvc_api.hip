@@ -199,6 +199,7 @@ kvc::GatherArgs gather_args(const kvc_params* p, const Items& it, int which, boo
     g.q_len = p->q_len; g.window = p->window;
     g.esize = esize_of(p->dtype);
     g.row_bytes = p->head_dim * g.esize;
+    g.out_head_bytes = p->out_stride_h * g.esize;
     return g;
 }
 
@@ -258,6 +259,12 @@ int run_items(const kvc_params* p, Items& it, void* workspace, size_t workspace_
             return fail(KVC_ERR_ALIGNMENT, "k / v / k_out / v_out not 16-byte aligned (item %d)", i);
         if (it.keep[i] < 0 || it.keep[i] > p->q_len - p->window) return fail(KVC_ERR_INVALID, "k=%d outside [0, q_len-window] (item %d)", it.keep[i], i);
         if (it.keep[i] > it.k_max) it.k_max = it.keep[i];
+    }
+    if (p->out_stride_h != 0) {
+        if (p->out_stride_h < (int64_t)(it.k_max + p->window) * p->head_dim)
+            return fail(KVC_ERR_INVALID, "out_stride_h %lld smaller than (k + window) * head_dim = %lld", (long long)p->out_stride_h,
+                        (long long)(it.k_max + p->window) * p->head_dim);
+        if ((p->out_stride_h * es) % 16) return fail(KVC_ERR_ALIGNMENT, "out_stride_h not a multiple of 16 bytes");
     }
     if (!scoring(p->method)) {
         for (int i = 0; i < it.n; ++i)

@@ -54,6 +54,7 @@ struct GatherArgs {
     PtrTable src, out, idx;                           // per item; idx entry may be null (identity)
     IntTable k;                                       // per item
     int64_t stride_b, stride_h, stride_l;             // elements
+    int64_t out_head_bytes;                           // bytes between heads of `out`; 0 = dense ((k + window) rows)
     int bsz, n_q_heads, group, q_len, window, k_max, row_bytes, esize, n_items;
 };
 

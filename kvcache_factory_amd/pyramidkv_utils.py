@@ -27,6 +27,7 @@ from . import _kvc
 VERBOSE = os.environ.get("KVC_VERBOSE", "0") == "1"
 TIE_MODE = os.environ.get("KVC_TIE_MODE", "torch_cpu")   # "torch_cpu" (reference-exact ties) | "canonical"
 BATCH_LAYERS = os.environ.get("KVC_BATCH_LAYERS", "1") == "1"   # patched forwards compress all layers in one call
+SPARE_ROWS = 256                                         # decode rows per head reserved behind the compressed prompt
 
 
 def _say(msg):
@@ -104,9 +105,11 @@ class PrefillBatch:
     def holds(self, tag):
         return any(e[0] is tag for e in self.entries)
 
-    def add(self, cluster, key_states, query_states, value_states, sink, tag=None):
+    def add(self, cluster, key_states, query_states, value_states, sink, tag=None, alloc=None):
         """True: taken (sink(kc, vc) runs at flush).  False: not batchable here (pass-through, H2O — whose scoring
-        needs every query row and is not launch-bound) — the caller runs cluster.update_kv itself."""
+        needs every query row and is not launch-bound) — the caller runs cluster.update_kv itself.
+        alloc(bsz, n_heads, capacity_rows, head_dim, dtype, device) -> (k_buf, v_buf): optional owner-provided output
+        buffers (a decode cache with spare rows); K' / V' are then written straight into them and sink gets views."""
         bsz, num_heads, q_len, head_dim = cluster._prefill_shapes(key_states, query_states)
         if q_len < cluster.max_capacity_prompt or cluster._method == _kvc.H2O:
             return False
@@ -121,7 +124,7 @@ class PrefillBatch:
         k, v = _kvc._last_dim_contig(key_states), _kvc._last_dim_contig(value_states)
         layout = (cluster._method, tuple(k.shape), k.stride(), v.stride(), k.dtype, k.device, num_heads, W,
                   cluster.kernel_size if scoring else 0, cluster.pooling if scoring else None)
-        self.entries.append((tag, layout, k, qw, v, n_keep, sink))
+        self.entries.append((tag, layout, k, qw, v, n_keep, sink, alloc))
         return True
 
     def flush(self):
@@ -132,9 +135,14 @@ class PrefillBatch:
         for layout, es in groups.items():
             method, _, _, _, _, _, num_heads, W, kernel_size, pooling = layout
             scoring = method != _kvc.STREAMINGLLM
+            outs = None
+            if all(e[7] is not None for e in es):             # one capacity for the group: one head stride per launch
+                k0 = es[0][2]
+                cap_rows = max(e[5] for e in es) + W + SPARE_ROWS
+                outs = [e[7](k0.shape[0], num_heads, cap_rows, k0.shape[3], k0.dtype, k0.device) for e in es]
             kc, vc = _kvc.compress_batch(method, [e[3] for e in es] if scoring else None, [e[2] for e in es],
                                          [e[4] for e in es], W, [e[5] for e in es], kernel_size, pooling, TIE_MODE,
-                                         q_rows="window" if scoring else "all", n_q_heads=num_heads)
+                                         q_rows="window" if scoring else "all", n_q_heads=num_heads, outs=outs)
             for e, a, b in zip(es, kc, vc):
                 e[6](a, b)
 

@@ -28,7 +28,7 @@ def oracle_compress(method, q, k, v, window, n_keep, kernel_size=5, pooling="avg
 
 
 def oracle_compress_batch(method, qs, ks, vs, window, keeps, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu",
-                          q_rows="all", n_q_heads=None, return_indices=False, dot_mode=None):
+                          q_rows="all", n_q_heads=None, return_indices=False, dot_mode=None, outs=None):
     """Stand-in for _kvc.compress_batch: the items one after the other through oracle_compress."""
     ko, vo, ix = [], [], []
     for i, (k, v) in enumerate(zip(ks, vs)):
@@ -39,5 +39,10 @@ def oracle_compress_batch(method, qs, ks, vs, window, keeps, kernel_size=5, pool
             full[:, :, -window:] = q
             q = full
         r = oracle_compress(method, q, k, v, window, keeps[i], kernel_size, pooling, tie_mode, n_q_heads, True)
+        if outs is not None:                                          # caller's buffers: fill the first rows, hand out views
+            kb, vb = outs[i]
+            rows = r[0].shape[2]
+            kb[:, :, :rows].copy_(r[0]); vb[:, :, :rows].copy_(r[1])
+            r = (kb[:, :, :rows], vb[:, :, :rows], r[2])
         ko.append(r[0]); vo.append(r[1]); ix.append(r[2])
     return (ko, vo, ix) if return_indices else (ko, vo)

@@ -24,11 +24,11 @@ def test_library_exports_every_declared_symbol(kvc):
     lib = ctypes.CDLL(kvc.LIB_PATH)
     for s in syms:
         assert getattr(lib, s) is not None
-    assert kvc.lib().kvc_version() == 1
+    assert kvc.lib().kvc_version() == 2
 
 
 def test_params_struct_matches_header(kvc):
-    """ctypes mirror has the header's field order and size (14 x int32 + 9 x int64 = 128 bytes)."""
+    """ctypes mirror has the header's field order and size (14 x int32 + 10 x int64 = 136 bytes)."""
     text = open(os.path.join(ROOT, "include", "kvc.h")).read()
     body = text[text.index("typedef struct kvc_params {"):text.index("} kvc_params;")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
@@ -36,7 +36,7 @@ def test_params_struct_matches_header(kvc):
     for decl in re.findall(r"int(?:32|64)_t\s+([^;]+);", body):
         fields += [f.strip() for f in decl.split(",")]
     assert fields == [f[0] for f in kvc.Params._fields_]
-    assert ctypes.sizeof(kvc.Params) == 14 * 4 + 9 * 8
+    assert ctypes.sizeof(kvc.Params) == 14 * 4 + 10 * 8
 
 
 def _p(kvc, **kw):

@@ -421,3 +421,33 @@ def test_kscan_batch_vs_call_stress(kvc, gpu_device):
         assert rc == 0, kvc.lib().kvc_last_error()
         torch.cuda.synchronize()
         assert all(torch.equal(a.view(torch.int16), b.view(torch.int16)) for a, b in zip(sc, ref))
+
+
+@pytest.mark.parametrize("tie", ["canonical", "torch_cpu"])
+def test_outputs_written_into_the_callers_cache_buffers(kvc, gpu_device, tie):
+    """kvc_params.out_stride_h (N1, decode side): K' / V' go straight into [bsz, H_q, capacity, D] buffers with spare rows
+    per head — fused gather (canonical, k <= 512), gather kernel (exact ties; k > 512), StreamingLLM copy — byte-identical
+    to the dense result in the first k + W rows, spare rows untouched; per call and batched."""
+    L, W = 3000, 8
+    qkv = [G.synth.make_qkv(32, 8, L, 128, torch.bfloat16, 800 + i, device=gpu_device) for i in range(3)]
+    keeps = [120, 600, 64]
+    cap = max(keeps) + W + 40
+
+    def bufs():
+        return (torch.full((1, 32, cap, 128), 7.0, dtype=torch.bfloat16, device=gpu_device),
+                torch.full((1, 32, cap, 128), -3.0, dtype=torch.bfloat16, device=gpu_device))
+    outs = [bufs() for _ in keeps]
+    bp = kvc.BatchPlan(kvc.SNAPKV, qkv, W, keeps, 7, "maxpool", tie, outs=outs)
+    ko, vo = bp.run()
+    for i, (q, k, v) in enumerate(qkv):
+        kd, vd = kvc.compress(kvc.SNAPKV, q, k, v, W, keeps[i], 7, "maxpool", tie)              # dense reference
+        rows = keeps[i] + W
+        assert ko[i].data_ptr() == outs[i][0].data_ptr() and torch.equal(ko[i], kd) and torch.equal(vo[i], vd)
+        assert bool((outs[i][0][:, :, rows:] == 7.0).all()) and bool((outs[i][1][:, :, rows:] == -3.0).all())
+        ob = bufs()
+        k1, v1 = kvc.compress(kvc.SNAPKV, q, k, v, W, keeps[i], 7, "maxpool", tie, out=ob)      # per call
+        assert torch.equal(k1, kd) and torch.equal(v1, vd) and bool((ob[0][:, :, rows:] == 7.0).all())
+        ob = bufs()
+        k2, v2 = kvc.compress(kvc.STREAMINGLLM, None, k, v, W, keeps[i], n_q_heads=32, out=ob)
+        ks, vs = kvc.compress(kvc.STREAMINGLLM, None, k, v, W, keeps[i], n_q_heads=32)
+        assert torch.equal(k2, ks) and torch.equal(v2, vs) and bool((ob[1][:, :, rows:] == -3.0).all())

@@ -203,7 +203,8 @@ def test_layer_batching_gives_the_per_layer_cache(cpu_backend, monkeypatch, meth
     batch_calls = []
 
     def spy_batch(method_, qs, ks, vs, window, keeps, *a, **kw):
-        batch_calls.append((len(ks), list(keeps), kw.get("q_rows"), None if qs is None else tuple(qs[0].shape)))
+        batch_calls.append((len(ks), list(keeps), kw.get("q_rows"), None if qs is None else tuple(qs[0].shape),
+                            None if kw.get("outs") is None else [o[0].data_ptr() for o in kw["outs"]]))
         return oracle_compress_batch(method_, qs, ks, vs, window, keeps, *a, **kw)
     monkeypatch.setattr(_kvc, "compress_batch", spy_batch)
     outs = {}
@@ -228,6 +229,10 @@ def test_layer_batching_gives_the_per_layer_cache(cpu_backend, monkeypatch, meth
         assert torch.equal(la.keys, lb.keys) and torch.equal(la.values, lb.values)
         assert la.get_seq_length() == lb.get_seq_length() == L + 2
     assert len(outs[True].past_key_values._kvc_pending) == 0
+    if method != "h2o":            # N1: the batched launch wrote K' / V' straight into the cache layers' own buffers
+        ptrs = batch_calls[0][4]
+        assert ptrs is not None and ptrs == [la._kbuf.data_ptr() for la in outs[True].past_key_values.layers]
+        assert all(la._kbuf.shape[2] == max(batch_calls[0][1]) + W + pu.SPARE_ROWS for la in outs[True].past_key_values.layers)
 
 
 def test_layer_batching_settles_an_unfinished_prefill(cpu_backend, monkeypatch):
@@ -253,3 +258,26 @@ def test_layer_batching_settles_an_unfinished_prefill(cpu_backend, monkeypatch):
         assert len(cache._kvc_pending) == 0 and layer.get_seq_length() == 101 and layer.keys.shape == (1, 32, 49, 128)
     finally:
         mp.replace_llama("fullkv")
+
+
+def test_decode_appends_in_place(cpu_backend):
+    """N1 (decode side): after the prefill the cache layer owns a buffer with spare rows; generated tokens are written
+    in place (stable storage, no torch.cat per token) and the filled part is handed out as a view — the same bytes a
+    cat-grown cache would hold; the buffer doubles when the spare rows run out."""
+    from kvcache_factory_amd.cache import CompressedDynamicLayer
+    g = torch.Generator().manual_seed(9)
+    k0, v0 = torch.randn(1, 4, 10, 8, generator=g), torch.randn(1, 4, 10, 8, generator=g)
+    layer = CompressedDynamicLayer()
+    layer.RESERVE = 3
+    layer.prefill(k0, v0, 100)
+    ref_k, ref_v = k0, v0
+    ptr = layer._kbuf.data_ptr()
+    for step in range(8):
+        kn, vn = torch.randn(1, 4, 1, 8, generator=g), torch.randn(1, 4, 1, 8, generator=g)
+        ko, vo = layer.update(kn, vn)
+        ref_k, ref_v = torch.cat([ref_k, kn], 2), torch.cat([ref_v, vn], 2)
+        assert torch.equal(ko, ref_k) and torch.equal(vo, ref_v) and layer.get_seq_length() == 101 + step
+        assert layer.get_mask_sizes(1) == (11 + step + 1, 0)
+        if step < 3:
+            assert layer._kbuf.data_ptr() == ptr                      # spare rows: same storage
+    assert layer._kbuf.data_ptr() != ptr and layer._kbuf.shape[2] >= 18  # grew by doubling
