@@ -416,6 +416,27 @@ def main():
                 del p2
             except Exception as e:
                 extra[f"tie_mode_{other}_error"] = str(e)
+            if a.mode == "batch":
+                # two prompts in flight: consecutive steps alternate between two HIP streams (own outputs and workspace
+                # each), so the latency-bound select of one prompt overlaps the K scan / softmax of the next
+                try:
+                    s2 = torch.cuda.Stream(device=dev)
+                    with torch.cuda.stream(s2):
+                        alt = BatchStep(cfg, dev, a.tie_mode, call_plans, ks)
+                    torch.cuda.synchronize(dev)
+                    pair = [plans[0], alt]
+                    for i in range(2):
+                        pair[i % 2].run()
+                    torch.cuda.synchronize(dev)
+                    n2 = 2 * half
+                    t0 = time.perf_counter()
+                    for i in range(n2):
+                        pair[i % 2].run()
+                    torch.cuda.synchronize(dev)
+                    extra["tokens_per_s_two_prompts_in_flight_2_streams"] = n2 * tokens_per_step / (time.perf_counter() - t0)
+                    del alt, pair
+                except Exception as e:
+                    extra["two_streams_error"] = str(e)
             if a.mode == "batch" and a.dot_mode == "exact":
                 try:
                     _kvc.DOT_MODE = "mfma16"
