@@ -451,3 +451,44 @@ def test_outputs_written_into_the_callers_cache_buffers(kvc, gpu_device, tie):
         k2, v2 = kvc.compress(kvc.STREAMINGLLM, None, k, v, W, keeps[i], n_q_heads=32, out=ob)
         ks, vs = kvc.compress(kvc.STREAMINGLLM, None, k, v, W, keeps[i], n_q_heads=32)
         assert torch.equal(k2, ks) and torch.equal(v2, vs) and bool((ob[1][:, :, rows:] == -3.0).all())
+
+
+@pytest.mark.parametrize("method", ["snapkv", "h2o", "streamingllm"])
+def test_batch_dimension_equals_separate_calls(kvc, gpu_device, method):
+    """bsz = 2 (the reference's tensor code is batch-agnostic, README TODO aside): each batch row compresses exactly
+    as it does alone — indices, K', V' — for the scored methods (both tie modes), H2O and StreamingLLM."""
+    L, W, keep = 520, 8, 56
+    rows = [G.synth.make_qkv(32, 8, L, 128, torch.bfloat16, 60 + b, device=gpu_device) for b in range(2)]
+    q, k, v = [torch.cat([r[i] for r in rows], 0).contiguous() for i in range(3)]
+    meth = METHOD[method]
+    for tie in ("canonical", "torch_cpu"):
+        kw = dict(n_q_heads=32, return_indices=True)
+        args = (W, keep, 7, "maxpool" if method == "snapkv" else None, tie)
+        both = kvc.compress(meth, q if method != "streamingllm" else None, k, v, *args, **kw)
+        for b, (qb, kb, vb) in enumerate(rows):
+            one = kvc.compress(meth, qb if method != "streamingllm" else None, kb, vb, *args, **kw)
+            assert torch.equal(both[0][b:b + 1], one[0]) and torch.equal(both[1][b:b + 1], one[1]) and torch.equal(both[2][b:b + 1], one[2])
+
+
+@pytest.mark.parametrize("tie", ["canonical", "torch_cpu"])
+def test_batched_call_replays_from_a_hip_graph(kvc, gpu_device, tie):
+    """The library only enqueues kernels on the given stream (no allocation, no synchronisation, attributes set on the
+    first eager call): a kvc_compress_batch captured into a HIP graph replays with identical results."""
+    L, W, keeps = 2048, 8, [120, 64, 300, 120]
+    qkv = [G.synth.make_qkv(32, 8, L, 128, torch.bfloat16, 40 + i, device=gpu_device) for i in range(len(keeps))]
+    bp = kvc.BatchPlan(kvc.SNAPKV, qkv, W, keeps, 7, "maxpool", tie, want_indices=True)
+    bp.run()
+    torch.cuda.synchronize()
+    want = [(a.clone(), b.clone(), c.clone()) for a, b, c in zip(bp.k_out, bp.v_out, bp.idx)]
+    side = torch.cuda.Stream(device=gpu_device)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        import ctypes
+        bp.run(ctypes.c_void_p(side.cuda_stream))
+    for _ in range(2):
+        for t in bp.k_out + bp.v_out + bp.idx:
+            t.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for (a, b, c), ko, vo, ix in zip(want, bp.k_out, bp.v_out, bp.idx):
+            assert torch.equal(a, ko) and torch.equal(b, vo) and torch.equal(c, ix)
