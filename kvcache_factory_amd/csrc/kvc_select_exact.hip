@@ -217,10 +217,13 @@ __device__ __forceinline__ void partial_sort_wave(const typename Dt<DT>::raw* s,
 // is at most 16 long with runs already ordered among themselves, so the final place of element i is
 // i - #(j in [i-15, i): key_j < key_i) + #(j in (i, i+15]: key_j > key_i) — 30 reads per element, all lanes at once.
 // ---------------------------------------------------------------------------------------------------------
+constexpr int kSmallRange = 1024;                        // partitions up to this many elements keep their lists in LDS
+constexpr size_t kSmallListBytes = (size_t)(kSmallRange / 2 + 2) * 8;
 struct WaveSel {
     u64* arr;
-    int* Lp;
-    int* Rp;
+    int* Lbig;                                           // position lists for any range (caller's workspace)
+    int* Rbig;
+    int* small;                                          // LDS lists for ranges <= kSmallRange, or null
     int lane;
     __device__ __forceinline__ static uint32_t key(u64 v) { return (uint32_t)(v >> 32); }
     __device__ __forceinline__ u64 get(int i) const { return uni(arr[i]); }
@@ -228,38 +231,76 @@ struct WaveSel {
     __device__ int partition(int first, int last, int pivot) {
         const uint32_t pk = key(get(pivot));
         const int cap = (last - first) / 2 + 2;
+        // the sort phase makes hundreds of small partitions: their lists live in LDS (a list round trip through the
+        // workspace costs a memory latency per partition)
+        const bool use_small = small != nullptr && last - first <= kSmallRange;
+        int* const Lp = use_small ? small : Lbig;
+        int* const Rp = use_small ? small + (kSmallRange / 2 + 2) : Rbig;
         int NL = 0, NR = 0;
-        for (int base = first; base < last; base += 64) {                 // left stoppers, ascending positions
-            const int i = base + lane;
-            const bool sl = i < last && !(key(arr[i]) > pk);
-            const u64 mask = __ballot(sl);
-            const int rank = NL + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-            if (sl && rank < cap) Lp[rank] = i;
-            NL += __builtin_popcountll(mask);
+        // eight 64-element chunks per trip, their loads issued together: when the array lives in the workspace (n > 18000)
+        // a chunk fetched on demand costs a memory round trip per 64 elements
+        constexpr int UF = 8;
+        for (int base = first; base < last; base += 64 * UF) {            // left stoppers, ascending positions
+            uint32_t kx[UF];
+#pragma unroll
+            for (int u = 0; u < UF; ++u) { const int i = base + u * 64 + lane; kx[u] = i < last ? key(arr[i]) : 0u; }
+#pragma unroll
+            for (int u = 0; u < UF; ++u) {
+                const int i = base + u * 64 + lane;
+                const bool sl = i < last && !(kx[u] > pk);
+                const u64 mask = __ballot(sl);
+                const int rank = NL + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+                if (sl && rank < cap) Lp[rank] = i;
+                NL += __builtin_popcountll(mask);
+            }
         }
-        for (int top = last; top > first; top -= 64) {                    // right stoppers, descending positions
-            const int i = top - 1 - lane;
-            const bool sr = i >= first && !(pk > key(arr[i]));
-            const u64 mask = __ballot(sr);
-            const int rank = NR + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-            if (sr && rank < cap) Rp[rank] = i;
-            NR += __builtin_popcountll(mask);
+        for (int top = last; top > first; top -= 64 * UF) {               // right stoppers, descending positions
+            uint32_t kx[UF];
+#pragma unroll
+            for (int u = 0; u < UF; ++u) { const int i = top - 1 - u * 64 - lane; kx[u] = i >= first ? key(arr[i]) : 0u; }
+#pragma unroll
+            for (int u = 0; u < UF; ++u) {
+                const int i = top - 1 - u * 64 - lane;
+                const bool sr = i >= first && !(pk > kx[u]);
+                const u64 mask = __ballot(sr);
+                const int rank = NR + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+                if (sr && rank < cap) Rp[rank] = i;
+                NR += __builtin_popcountll(mask);
+            }
         }
         __syncthreads();
         int lim = NL < NR ? NL : NR;
         if (lim > cap) lim = cap;
-        int T = 0;
-        for (int t0 = 0; t0 < lim; t0 += 64) {                            // l_t < r_t holds for a prefix of t
-            const int t = t0 + lane;
-            const bool ok = t < lim && Lp[t] < Rp[t];
-            const u64 bad = ~__ballot(ok);
-            if (bad == 0) { T += 64; continue; }
-            T += __builtin_ctzll(bad);
-            break;
+        // l_t < r_t holds exactly for a prefix of t (l ascending, r descending): T by bisection over the wave — 64 probes
+        // per step, log64(lim) dependent list reads instead of lim / 64
+        int T;
+        {
+            int lo_t = 0, hi_t = lim;                                     // answer in [lo_t, hi_t]
+            while (hi_t - lo_t > 0) {
+                const int span = hi_t - lo_t, step = (span + 63) / 64;    // probe t = lo_t + lane * step
+                const int t = lo_t + lane * step;
+                const bool ok = t < hi_t && Lp[t] < Rp[t];
+                const u64 okm = __ballot(ok);
+                const int good = __builtin_popcountll(okm);               // probes 0 .. good-1 hold (prefix property)
+                if (good == 0) { hi_t = lo_t; break; }
+                const int last_ok = lo_t + (good - 1) * step;
+                lo_t = last_ok + 1;
+                const int next_bad = lo_t + step - 1;                     // the first failing probe, or the end
+                hi_t = next_bad < hi_t ? next_bad : hi_t;
+                if (step == 1) break;
+            }
+            T = lo_t;
         }
-        for (int t0 = 0; t0 < T; t0 += 64) {
-            const int t = t0 + lane;
-            if (t < T) { const int l = Lp[t], r = Rp[t]; const u64 a = arr[l], b = arr[r]; arr[l] = b; arr[r] = a; }
+        constexpr int US = 4;                                             // swaps: four pairs per lane per trip, loads grouped
+        for (int t0 = 0; t0 < T; t0 += 64 * US) {
+            int l[US], r[US];
+            u64 av[US], bv[US];
+#pragma unroll
+            for (int u = 0; u < US; ++u) { const int t = t0 + u * 64 + lane; l[u] = t < T ? Lp[t] : -1; r[u] = t < T ? Rp[t] : -1; }
+#pragma unroll
+            for (int u = 0; u < US; ++u) if (l[u] >= 0) { av[u] = arr[l[u]]; bv[u] = arr[r[u]]; }
+#pragma unroll
+            for (int u = 0; u < US; ++u) if (l[u] >= 0) { arr[l[u]] = bv[u]; arr[r[u]] = av[u]; }
         }
         const int lnext = T < NL ? uni(Lp[T]) : 0x7fffffff;
         const int rlast = T > 0 ? uni(Rp[T - 1]) : 0x7fffffff;
@@ -333,6 +374,220 @@ struct WaveSel {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------
+// WaveHeap9: the same heap for up to 511 nodes (16-bit dtypes, packed 32-bit nodes): budgets 129..511 in the
+// partial_sort regime (e.g. cap 256 at 16k / 32k, PyramidKV's small layers at 32k), which the scalar program runs at
+// ~2400 cycles per step.
+//   levels 0-5 (nodes 0..62): one node per lane, path by the "which child" mask, exactly as WaveHeap;
+//   levels 6-8: node 63+j and its six descendants (127+2j, 128+2j, 255+4j .. 258+4j) are PRIVATE to lane j, in
+//   registers: once the path leaves the top part it is that lane's own business — no communication.
+// arr[] (LDS) mirrors nodes 0..126 so that the lanes of levels 0-5 can fetch their children (level 6 = the p0 of the
+// lanes below them).
+// ---------------------------------------------------------------------------------------------------------
+struct WaveHeap9 {
+    typedef HeapNode<uint32_t> N;
+    uint32_t top;          // node `lane` (lanes 0..62)
+    uint32_t xl, xr;       // its children
+    uint32_t p0, p1, p2, p3, p4, p5, p6;   // private sub-heap of lane j: nodes 63+j; 127+2j, 128+2j; 255+4j..258+4j
+    u64 A, R, M;
+    uint32_t* arr;
+    int lane;
+    // what the private walk of this lane found for the current step (valid for every lane, used for one)
+    int d1, d2;            // chosen child at level 7 (1 | 2) and at level 8 (slot 3..6)
+    uint32_t v1, v2;
+    bool has1, has2;
+
+    __device__ __forceinline__ int q1() const { return 127 + 2 * lane; }
+    __device__ __forceinline__ int q3() const { return 255 + 4 * lane; }
+    __device__ __forceinline__ uint32_t slot(int sl) const {
+        return sl == 0 ? p0 : sl == 1 ? p1 : sl == 2 ? p2 : sl == 3 ? p3 : sl == 4 ? p4 : sl == 5 ? p5 : p6;
+    }
+    __device__ __forceinline__ void set_slot(int sl, uint32_t v) {
+        p0 = sl == 0 ? v : p0; p1 = sl == 1 ? v : p1; p2 = sl == 2 ? v : p2; p3 = sl == 3 ? v : p3;
+        p4 = sl == 4 ? v : p4; p5 = sl == 5 ? v : p5; p6 = sl == 6 ? v : p6;
+    }
+    // node index -> value (wave-uniform index)
+    __device__ __forceinline__ uint32_t node(int i) const {
+        if (i < 63) return N::rdlane(top, i);
+        if (i < 127) return N::rdlane(p0, i - 63);
+        if (i < 255) { const int l = (i - 127) >> 1; return ((i - 127) & 1) ? N::rdlane(p2, l) : N::rdlane(p1, l); }
+        const int l = (i - 255) >> 2, w = (i - 255) & 3;
+        return w == 0 ? N::rdlane(p3, l) : w == 1 ? N::rdlane(p4, l) : w == 2 ? N::rdlane(p5, l) : N::rdlane(p6, l);
+    }
+    __device__ __forceinline__ void force_bit(int len) {             // a top node with only a left child moves left
+        if (len >= 2 && (len & 1) == 0 && ((len - 2) >> 1) < 63) M |= 1ull << ((len - 2) >> 1);
+    }
+    // the private walk from this lane's level-6 node: choices by libstdc++'s rule (right child unless it sorts before
+    // the left one; a lone left child is taken)
+    __device__ __forceinline__ void walk(int len) {
+        const int a1 = q1(), a3 = q3();
+        has1 = a1 < len;
+        const bool r1 = a1 + 1 < len && !N::gt(p2, p1);            // move right at level 7
+        d1 = r1 ? 2 : 1;
+        v1 = r1 ? p2 : p1;
+        const int al = r1 ? a3 + 2 : a3;                             // left grandchild under the chosen child
+        const uint32_t cl = r1 ? p5 : p3, cr = r1 ? p6 : p4;
+        has2 = has1 && al < len;
+        const bool r2 = al + 1 < len && !N::gt(cr, cl);
+        d2 = (r1 ? 5 : 3) + (r2 ? 1 : 0);
+        v2 = r2 ? cr : cl;
+    }
+    // deepest private path node (depth 2, 1, or 0 = the level-6 node itself when `with0`) that does not sort before
+    // `value`; -1 if none
+    __device__ __forceinline__ int private_stop(uint32_t value, bool with0) const {
+        if (has2 && !N::gt(v2, value)) return 2;
+        if (has1 && !N::gt(v1, value)) return 1;
+        if (with0 && !N::gt(p0, value)) return 0;
+        return -1;
+    }
+    // shift the private path up to depth sp and drop `value` there (this lane only)
+    __device__ __forceinline__ void private_apply(int sp, uint32_t value, bool mine) {
+        if (!mine) return;
+        if (sp == 0) { p0 = value; return; }
+        p0 = v1;
+        if (sp == 1) { set_slot(d1, value); return; }
+        set_slot(d1, v2);
+        set_slot(d2, value);
+    }
+    // __make_heap inside the private sub-heaps: every level-7 node, then every level-6 node — disjoint subtrees, so all
+    // lanes at once give the array the sequential loop gives
+    __device__ __forceinline__ void private_make_heap(int len) {
+        {   // level 7: nodes q1, q2 with their (at most two) level-8 children
+            const int a1 = q1(), a3 = q3();
+#pragma unroll
+            for (int side = 1; side >= 0; --side) {                   // higher index first, like the sequential loop
+                const int a = a1 + side, al = a3 + 2 * side;
+                const uint32_t cur = side ? p2 : p1, cl = side ? p5 : p3, cr = side ? p6 : p4;
+                if (a < len && al < len) {
+                    const bool r = al + 1 < len && !N::gt(cr, cl);
+                    const uint32_t ch = r ? cr : cl;
+                    if (!N::gt(ch, cur)) {                             // __push_heap stops at the child: the two swap
+                        set_slot(side ? 2 : 1, ch);
+                        set_slot((side ? 5 : 3) + (r ? 1 : 0), cur);
+                    }
+                }
+            }
+        }
+        if (63 + lane < len) {                                        // level 6: the whole private sub-heap
+            walk(len);
+            const uint32_t value = p0;
+            int sp = private_stop(value, false);
+            if (sp < 0) sp = 0;
+            private_apply(sp, value, true);
+        }
+    }
+    __device__ __forceinline__ void init(uint32_t* lds, int len) {   // top / p0..p6 set by the caller
+        lane = threadIdx.x;
+        arr = lds;
+        A = R = 0;
+        for (int c = lane; c > 0;) { const int p = (c - 1) >> 1; A |= 1ull << p; if (c & 1) R |= 1ull << p; c = p; }
+        private_make_heap(len);
+        if (lane < 63) arr[lane] = top;
+        arr[63 + lane] = p0;
+        arr[127 + lane] = 0;                                          // (lane 63 reads arr[127], arr[128] as "children")
+        __syncthreads();
+        xl = arr[2 * lane + 1]; xr = arr[2 * lane + 2];
+        M = __ballot(N::gt(xr, xl));
+        force_bit(len);
+    }
+    // __adjust_heap(first, t, len, value) for a node t of the top part (t <= 62), with its __push_heap.
+    __device__ __forceinline__ void adjust(int t, u64 At, int len, uint32_t value) {
+        const u64 in_top = len >= 63 ? 0x7fffffffffffffffull : ((1ull << len) - 1);
+        const bool onp = lane == t || (((A >> t) & 1) && (((M ^ R) & A & ~At) == 0));
+        const u64 on_top = __ballot(onp) & in_top;
+        // does the path leave the top part?  the on-path level-5 node (31..62) and its chosen level-6 child
+        const u64 m5 = on_top & 0x7fffffff80000000ull;
+        int j6 = -1;
+        if (m5) {
+            const int l5 = __builtin_ctzll(m5);
+            const int c6 = 2 * l5 + 2 - (int)((M >> l5) & 1);
+            if (c6 < len) j6 = c6 - 63;
+        }
+        int sp = -1;
+        if (j6 >= 0) {
+            walk(len);
+            sp = __builtin_amdgcn_readlane(private_stop(value, true), j6);
+        }
+        const u64 g = __ballot(N::gt(top, value));
+        const u64 c_top = on_top & ~g & ~(1ull << t);
+        const int stop = c_top ? 63 - __builtin_clzll(c_top) : t;
+        const u64 below = (1ull << stop) - 1;
+        const u64 take = sp >= 0 ? on_top : (on_top & below);
+        const u64 eq = sp >= 0 ? 0ull : (1ull << stop);
+        const uint32_t child = lane_sel(xr, xl, M);
+        uint32_t vv = value;
+        asm volatile("" : "+v"(vv));
+        top = lane_sel(lane_sel(top, child, take), vv, eq);
+        private_apply(sp, value, sp >= 0 && lane == j6);
+        if (lane < 63) arr[lane] = top;
+        arr[63 + lane] = p0;
+        asm volatile("" ::: "memory");                                  // one wave, LDS in order
+        xl = arr[2 * lane + 1]; xr = arr[2 * lane + 2];
+        M = __ballot(N::gt(xr, xl));
+        force_bit(len);
+    }
+};
+
+// std::partial_sort for 128 < k <= 511 (16-bit dtypes).
+template <int DT>
+__device__ __forceinline__ void partial_sort_wave9(const typename Dt<DT>::raw* s, int n, int k, uint32_t* lds, int64_t* out) {
+    typedef HeapNode<uint32_t> N;
+    const int lane = threadIdx.x;
+    WaveHeap9 H;
+    auto ld = [&](int i) -> uint32_t { return i < k ? N::make(Key<DT>::of(s[i]), i) : 0u; };
+    H.lane = lane;
+    H.top = lane < 63 ? ld(lane) : 0u;
+    H.p0 = ld(63 + lane);
+    H.p1 = ld(127 + 2 * lane); H.p2 = ld(128 + 2 * lane);
+    H.p3 = ld(255 + 4 * lane); H.p4 = ld(256 + 4 * lane); H.p5 = ld(257 + 4 * lane); H.p6 = ld(258 + 4 * lane);
+    H.init(lds, k);
+    // __make_heap, the top part (the private levels are done in init)
+    const int t_hi = (k - 2) / 2 < 62 ? (k - 2) / 2 : 62;
+    for (int t = t_hi; t >= 0; --t) {
+        const uint32_t a0 = __builtin_amdgcn_readlane((uint32_t)H.A, t), a1 = __builtin_amdgcn_readlane((uint32_t)(H.A >> 32), t);
+        H.adjust(t, ((u64)a1 << 32) | a0, k, N::rdlane(H.top, t));
+    }
+    // __heap_select
+    uint32_t root = N::key(N::rdlane(H.top, 0));
+    constexpr int U = 8;
+    uint32_t cur[U], nxt[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) { const int i = k + j * 64 + lane; cur[j] = i < n ? Key<DT>::of(s[i]) : 0u; }
+    for (int base = k; base < n; base += U * 64) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) { const int i = base + (U + j) * 64 + lane; nxt[j] = i < n ? Key<DT>::of(s[i]) : 0u; }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int i0 = base + j * 64;
+            u64 pending = __ballot(i0 + lane < n && cur[j] > root);
+            while (pending) {
+                const int src = __builtin_ctzll(pending);
+                pending &= pending - 1;
+                const uint32_t kk = __builtin_amdgcn_readlane(cur[j], src);
+                if (kk > root) {
+                    H.adjust(0, 0, k, N::make(kk, i0 + src));
+                    root = N::key(N::rdlane(H.top, 0));
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) cur[j] = nxt[j];
+    }
+    // __sort_heap
+    uint32_t* res = lds + 192;
+    for (int last = k - 1; last >= 1; --last) {
+        const uint32_t value = H.node(last), topv = N::rdlane(H.top, 0);
+        if (lane == 0) res[last] = topv;
+        H.force_bit(last);
+        H.adjust(0, 0, last, value);
+    }
+    if (lane == 0) res[0] = H.top;
+    __syncthreads();
+    for (int t = lane; t < k; t += 64) out[t] = N::index(res[t]);
+}
+constexpr int kWaveHeap9MaxK = 511;
+constexpr size_t kWaveHeap9Lds = (192 + 512) * 4;
+
 constexpr int kWaveHeapMaxK = 128;
 constexpr size_t kWaveHeapLds = (192 + 128) * 8;
 
@@ -354,6 +609,8 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const SelectArgs a, u6
     if (use_partial_sort && k <= kWaveHeapMaxK) {
         if constexpr (Key<DT>::bits == 16) partial_sort_wave<DT, uint32_t>(s, n, k, reinterpret_cast<uint32_t*>(lds_arr), out);   // n <= 65536
         else partial_sort_wave<DT, u64>(s, n, k, lds_arr, out);
+    } else if (use_partial_sort && k <= kWaveHeap9MaxK && Key<DT>::bits == 16) {
+        if constexpr (Key<DT>::bits == 16) partial_sort_wave9<DT>(s, n, k, reinterpret_cast<uint32_t*>(lds_arr), out);
     } else if (use_partial_sort) {
         // heap of the first k in LDS; the tail is streamed 64 at a time
         Arr H{lds_arr};
@@ -391,18 +648,32 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const SelectArgs a, u6
         for (int t = lane; t < k; t += 64) out[t] = (int64_t)(lds_arr[t] & 0xffffffffull);
     } else {
         // scratch per (item, head): [n u64 array, when it does not fit in LDS][2 x (n/2 + 2) int position lists]
+        const bool small_lists = (arr_in_lds & 2) != 0;
+        arr_in_lds &= 1;
         const int64_t per_head = (arr_in_lds ? 0 : (int64_t)n) + (n / 2 + 2);
         u64* const hs = gscratch + ((int64_t)item * a.heads + head) * per_head;
         u64* arr = arr_in_lds ? lds_arr : hs;
         int* const lists = reinterpret_cast<int*>(hs + (arr_in_lds ? 0 : n));
+        // LDS behind the array region (n elements, or the k_max - 1 being sorted): lists for small partitions
+        int* const small = small_lists ? reinterpret_cast<int*>(lds_arr + (arr_in_lds ? n : a.k_max)) : nullptr;
         for (int i = lane; i < n; i += 64) arr[i] = ((u64)Key<DT>::of(s[i]) << 32) | (uint32_t)i;
         __syncthreads();
-        WaveSel S{arr, lists, lists + (n / 2 + 2), lane};
+        WaveSel S{arr, lists, lists + (n / 2 + 2), small, lane};
         // std::nth_element(first, first + k - 1, last)
         if (k - 1 != n) S.introselect(0, k - 1, n, lg_(n) * 2);
-        // std::sort(first, first + k - 1), written to out as it is placed; the nth element follows
-        S.sort_to(0, k - 1, stack, out);
-        if (lane == 0) out[k - 1] = (int64_t)(arr[k - 1] & 0xffffffffull);
+        // std::sort(first, first + k - 1), written to out as it is placed; the nth element follows.  When the array lives
+        // in the workspace the k - 1 leading elements move to LDS first: the sort makes hundreds of small partitions, each
+        // a handful of dependent accesses — a memory round trip apiece on the workspace copy.
+        const u64 nth = arr[k - 1];
+        if (!arr_in_lds && k - 1 > 0) {
+            for (int i = lane; i < k - 1; i += 64) lds_arr[i] = arr[i];
+            __syncthreads();
+            WaveSel S2{lds_arr, lists, lists + (n / 2 + 2), small, lane};
+            S2.sort_to(0, k - 1, stack, out);
+        } else {
+            S.sort_to(0, k - 1, stack, out);
+        }
+        if (lane == 0) out[k - 1] = (int64_t)(nth & 0xffffffffull);
     }
 }
 
@@ -418,13 +689,20 @@ static int launch_exact_t(const SelectArgs& a, void* scratch, hipStream_t st) {
     bool any_nth = false;
     for (int i = 0; i < a.n_items; ++i) any_nth = any_nth || !((int64_t)a.k.v[i] * 64 <= (int64_t)a.n);
     const int in_lds = !any_nth || a.n <= 18000;
-    const size_t elems = in_lds ? (any_nth ? (size_t)a.n : (size_t)a.k_max) : (size_t)a.k_max;
-    const size_t lds = 1152 + (elems * 8 > kWaveHeapLds ? elems * 8 : kWaveHeapLds);
+    // LDS: the whole array (nth_element items, n <= 18000), or the heap of k_max (partial_sort) / the k_max - 1 elements
+    // being sorted; plus 4 KB of lists for small partitions — unless that costs a resident wave per CU (160 KB of LDS, one
+    // wave = one workgroup here: these kernels are latency-bound, a second round of workgroups doubles their time)
+    size_t body = (in_lds && any_nth) ? (size_t)a.n * 8 : (size_t)a.k_max * 8;
+    if (body < kWaveHeap9Lds) body = kWaveHeap9Lds;                 // (>= kWaveHeapLds)
+    const bool small_lists = any_nth && (160 * 1024) / (1152 + body + kSmallListBytes) == (160 * 1024) / (1152 + body) &&
+                             1152 + body + kSmallListBytes <= 150 * 1024;
+    if (small_lists) body += kSmallListBytes;
+    const size_t lds = 1152 + body;
     if (any_nth && !scratch) return KVC_ERR_WORKSPACE;
     static LdsCache lds_cache = {};
     if (ensure_lds(reinterpret_cast<const void*>(&select_exact_kernel<DT>), lds, lds_cache) != 0) return KVC_ERR_HIP;
     hipLaunchKernelGGL((select_exact_kernel<DT>), dim3((unsigned)a.heads, (unsigned)a.n_items), dim3(64), lds, st, a,
-                       reinterpret_cast<u64*>(scratch), in_lds);
+                       reinterpret_cast<u64*>(scratch), in_lds | (small_lists ? 2 : 0));
     return 0;
 }
 

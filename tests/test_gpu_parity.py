@@ -359,7 +359,8 @@ def _tie_heavy_scores(heads, n, dtype, seed, levels):
 
 
 @pytest.mark.parametrize("n,k", [(300, 1), (300, 2), (300, 3), (300, 4), (8192, 64), (8192, 65), (8192, 127), (8192, 128),   # partial_sort, WaveHeap
-                                 (16384, 129), (16384, 256),                                                                 # partial_sort, k > 128 (scalar heap)
+                                 (16384, 129), (16384, 130), (16384, 191), (16384, 256), (24000, 375), (32768, 300),         # partial_sort, 128 < k <= 511: WaveHeap9
+                                 (32768, 510), (32768, 511), (32768, 512), (65536, 1024),                                    # ... and the scalar heap beyond
                                  (300, 5), (300, 17), (300, 150), (300, 299), (300, 300), (1000, 16), (1000, 999),           # nth_element + sort
                                  (18000, 282), (18001, 2000), (20000, 313), (40000, 5000)])                                  # array in LDS / in the workspace
 @pytest.mark.parametrize("dtype,levels", [(torch.bfloat16, 3), (torch.bfloat16, 40), (torch.float16, 500), (torch.float32, 7)])
