@@ -228,19 +228,10 @@ struct WaveSel {
     __device__ __forceinline__ static uint32_t key(u64 v) { return (uint32_t)(v >> 32); }
     __device__ __forceinline__ u64 get(int i) const { return uni(arr[i]); }
 
-    __device__ int partition(int first, int last, int pivot) {
-        const uint32_t pk = key(get(pivot));
-        const int cap = (last - first) / 2 + 2;
-        // the sort phase makes hundreds of small partitions: their lists live in LDS (a list round trip through the
-        // workspace costs a memory latency per partition)
-        const bool use_small = small != nullptr && last - first <= kSmallRange;
-        int* const Lp = use_small ? small : Lbig;
-        int* const Rp = use_small ? small + (kSmallRange / 2 + 2) : Rbig;
-        int NL = 0, NR = 0;
-        // eight 64-element chunks per trip, their loads issued together: when the array lives in the workspace (n > 18000)
-        // a chunk fetched on demand costs a memory round trip per 64 elements
-        constexpr int UF = 8;
-        for (int base = first; base < last; base += 64 * UF) {            // left stoppers, ascending positions
+    // the two compaction passes of partition(): left stoppers in ascending, right stoppers in descending position order
+    template <int UF>
+    __device__ __forceinline__ void scan(int first, int last, uint32_t pk, int cap, int* Lp, int* Rp, int& NL, int& NR) {
+        for (int base = first; base < last; base += 64 * UF) {
             uint32_t kx[UF];
 #pragma unroll
             for (int u = 0; u < UF; ++u) { const int i = base + u * 64 + lane; kx[u] = i < last ? key(arr[i]) : 0u; }
@@ -254,7 +245,7 @@ struct WaveSel {
                 NL += __builtin_popcountll(mask);
             }
         }
-        for (int top = last; top > first; top -= 64 * UF) {               // right stoppers, descending positions
+        for (int top = last; top > first; top -= 64 * UF) {
             uint32_t kx[UF];
 #pragma unroll
             for (int u = 0; u < UF; ++u) { const int i = top - 1 - u * 64 - lane; kx[u] = i >= first ? key(arr[i]) : 0u; }
@@ -268,6 +259,35 @@ struct WaveSel {
                 NR += __builtin_popcountll(mask);
             }
         }
+    }
+    template <int US>
+    __device__ __forceinline__ void swap_pairs(int T, const int* Lp, const int* Rp) {
+        for (int t0 = 0; t0 < T; t0 += 64 * US) {
+            int l[US], r[US];
+            u64 av[US], bv[US];
+#pragma unroll
+            for (int u = 0; u < US; ++u) { const int t = t0 + u * 64 + lane; l[u] = t < T ? Lp[t] : -1; r[u] = t < T ? Rp[t] : -1; }
+#pragma unroll
+            for (int u = 0; u < US; ++u) if (l[u] >= 0) { av[u] = arr[l[u]]; bv[u] = arr[r[u]]; }
+#pragma unroll
+            for (int u = 0; u < US; ++u) if (l[u] >= 0) { arr[l[u]] = bv[u]; arr[r[u]] = av[u]; }
+        }
+    }
+    __device__ int partition(int first, int last, int pivot) {
+        const uint32_t pk = key(get(pivot));
+        const int cap = (last - first) / 2 + 2;
+        // the sort phase makes hundreds of small partitions: their lists live in LDS (a list round trip through the
+        // workspace costs a memory latency per partition)
+        const bool use_small = small != nullptr && last - first <= kSmallRange;
+        int* const Lp = use_small ? small : Lbig;
+        int* const Rp = use_small ? small + (kSmallRange / 2 + 2) : Rbig;
+        int NL = 0, NR = 0;
+        // Loads are grouped UF chunks of 64 elements at a time: a long range in the workspace (n > 18000) is bound by memory
+        // round trips, a short one (the hundreds of sort partitions) by the instructions of the padded trips.
+        const int m = last - first;
+        if (m > 8192) scan<16>(first, last, pk, cap, Lp, Rp, NL, NR);
+        else if (m > 256) scan<4>(first, last, pk, cap, Lp, Rp, NL, NR);
+        else scan<1>(first, last, pk, cap, Lp, Rp, NL, NR);
         __syncthreads();
         int lim = NL < NR ? NL : NR;
         if (lim > cap) lim = cap;
@@ -291,17 +311,7 @@ struct WaveSel {
             }
             T = lo_t;
         }
-        constexpr int US = 4;                                             // swaps: four pairs per lane per trip, loads grouped
-        for (int t0 = 0; t0 < T; t0 += 64 * US) {
-            int l[US], r[US];
-            u64 av[US], bv[US];
-#pragma unroll
-            for (int u = 0; u < US; ++u) { const int t = t0 + u * 64 + lane; l[u] = t < T ? Lp[t] : -1; r[u] = t < T ? Rp[t] : -1; }
-#pragma unroll
-            for (int u = 0; u < US; ++u) if (l[u] >= 0) { av[u] = arr[l[u]]; bv[u] = arr[r[u]]; }
-#pragma unroll
-            for (int u = 0; u < US; ++u) if (l[u] >= 0) { arr[l[u]] = bv[u]; arr[r[u]] = av[u]; }
-        }
+        if (T > 2048) swap_pairs<8>(T, Lp, Rp); else if (T > 128) swap_pairs<2>(T, Lp, Rp); else swap_pairs<1>(T, Lp, Rp);
         const int lnext = T < NL ? uni(Lp[T]) : 0x7fffffff;
         const int rlast = T > 0 ? uni(Rp[T - 1]) : 0x7fffffff;
         __syncthreads();
