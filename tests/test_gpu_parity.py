@@ -493,3 +493,45 @@ def test_batched_call_replays_from_a_hip_graph(kvc, gpu_device, tie):
         torch.cuda.synchronize()
         for (a, b, c), ko, vo, ix in zip(want, bp.k_out, bp.v_out, bp.idx):
             assert torch.equal(a, ko) and torch.equal(b, vo) and torch.equal(c, ix)
+
+
+def _random_cases(n_cases, seed):
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))        # noqa: E731
+    cases = []
+    for _ in range(n_cases):
+        D = (64, 128)[ri(0, 1)]
+        hkv = (1, 2, 4, 8)[ri(0, 3)]
+        grp = (1, 2, 4, 8)[ri(0, 3)]
+        W = (4, 8, 8, 16, 32, 64, 12)[ri(0, 6)]
+        L = ri(W + 40, 2600)
+        kernel = (1, 3, 5, 7, 9, 15)[ri(0, 5)]
+        pooling = ("maxpool", "avgpool")[ri(0, 1)]
+        dtype = (torch.bfloat16, torch.float16, torch.float32)[ri(0, 2)]
+        keep = ri(1, min(L - W, 700))
+        items = (1, 1, 5)[ri(0, 2)]                                              # 5 x heads >= 128 picks the fused softmax form for most
+        cases.append((D, hkv, grp, W, L, kernel, pooling, dtype, keep, items))
+    return cases
+
+
+@pytest.mark.parametrize("case", _random_cases(int(__import__("os").environ.get("KVC_SWEEP_CASES", 36)), int(__import__("os").environ.get("KVC_SWEEP_SEED", 2024))), ids=lambda c: "D%d_kv%d_g%d_W%d_L%d_k%d_%s_%s_keep%d_x%d" % (
+    c[0], c[1], c[2], c[3], c[4], c[5], c[6], str(c[7]).split(".")[-1], c[8], c[9]))
+def test_random_shapes_end_to_end_vs_oracle(kvc, oracle, gpu_device, case):
+    """Seeded sweep over head_dim, GQA group, window (incl. W % 4 != 0 and W = 64), length, pooling kernel, dtype, budget
+    and batch size: kvc_compress / kvc_compress_batch == the oracle's product arithmetic — indices (both tie modes) and
+    K' / V' bytes — for every item."""
+    D, hkv, grp, W, L, kernel, pooling, dtype, keep, items = case
+    hq = hkv * grp
+    qkv = [G.synth.make_qkv(hq, hkv, L, D, dtype, 5000 + 17 * i + L, device=gpu_device) for i in range(items)]
+    for tie, otie in (("canonical", oracle.TIES_CANON), ("torch_cpu", oracle.TIES_TORCH)):
+        if items == 1:
+            got = [kvc.compress(kvc.SNAPKV, *qkv[0], W, keep, kernel, pooling, tie, return_indices=True)]
+        else:
+            bp = kvc.BatchPlan(kvc.SNAPKV, qkv, W, [keep] * items, kernel, pooling, tie, want_indices=True)
+            ko, vo = bp.run()
+            got = list(zip(ko, vo, bp.idx))
+        for (q, k, v), (kg, vg, ig) in zip(qkv, got):
+            ko_, vo_, io_, _ = oracle.compress(q.cpu(), k.cpu(), v.cpu(), W, keep, kernel, pooling, dot_mode=oracle.DOT_CHAIN,
+                                               sum_mode=oracle.SUM_KVC, tie_mode=otie)
+            assert torch.equal(ig[0].cpu(), io_)
+            assert torch.equal(G.bits(kg.cpu()), G.bits(ko_)) and torch.equal(G.bits(vg.cpu()), G.bits(vo_))
