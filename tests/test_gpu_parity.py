@@ -535,3 +535,35 @@ def test_random_shapes_end_to_end_vs_oracle(kvc, oracle, gpu_device, case):
                                                sum_mode=oracle.SUM_KVC, tie_mode=otie)
             assert torch.equal(ig[0].cpu(), io_)
             assert torch.equal(G.bits(kg.cpu()), G.bits(ko_)) and torch.equal(G.bits(vg.cpu()), G.bits(vo_))
+
+
+def _random_h2o_cases(n_cases, seed):
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))        # noqa: E731
+    out = []
+    for _ in range(n_cases):
+        W = (4, 8, 16, 32)[ri(0, 3)]
+        L = ri(W + 20, 700)
+        out.append(((64, 128)[ri(0, 1)], (1, 2, 4)[ri(0, 2)], (1, 2, 4)[ri(0, 2)], W, L,
+                    (torch.bfloat16, torch.float16, torch.float32)[ri(0, 2)], ri(1, min(L - W, 200))))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_h2o_cases(14, 77), ids=lambda c: "D%d_kv%d_g%d_W%d_L%d_%s_keep%d" % (
+    c[0], c[1], c[2], c[3], c[4], str(c[5]).split(".")[-1], c[6]))
+def test_random_shapes_h2o_and_streaming_vs_oracle(kvc, oracle, gpu_device, case):
+    """Seeded sweep for the two other methods: H2O (all query rows, torch-order sums; wide and one-element softmax forms
+    by L % 8) scores bit-exact and the compressed K' / V' / indices equal to the oracle; StreamingLLM copies."""
+    D, hkv, grp, W, L, dtype, keep = case
+    hq = hkv * grp
+    q, k, v = G.synth.make_qkv(hq, hkv, L, D, dtype, 9000 + L, device=gpu_device)
+    sc_o = oracle.scores(q.cpu(), k.cpu(), W, 7, "avgpool", full_rows=True, dot_mode=oracle.DOT_CHAIN, sum_mode=oracle.SUM_TORCH16)
+    sc_g = kvc.scores(kvc.H2O, q, k, W, 7, None)
+    assert torch.equal(G.bits(sc_g[0]), G.bits(sc_o))
+    kg, vg, ig = kvc.compress(kvc.H2O, q, k, v, W, keep, 7, None, "torch_cpu", return_indices=True)
+    io_, _ = oracle.topk(sc_o, keep, oracle.TIES_TORCH)
+    assert torch.equal(ig[0].cpu(), io_)
+    assert torch.equal(G.bits(kg.cpu()), G.bits(oracle.gather(k.cpu(), io_, W, hq)))
+    ks, vs = kvc.compress(kvc.STREAMINGLLM, None, k, v, W, keep, n_q_heads=hq)
+    ko_, vo_, _ = oracle.streaming(k.cpu(), v.cpu(), W, keep, hq)
+    assert torch.equal(G.bits(ks.cpu()), G.bits(ko_)) and torch.equal(G.bits(vs.cpu()), G.bits(vo_))
