@@ -131,3 +131,11 @@ def test_product_never_imports_the_oracle():
             "kvcache_factory_amd.mistral_model, kvcache_factory_amd.synth; "
             "bad = [m for m in sys.modules if m.split('.')[0] == 'oracle']; assert not bad, bad" % ROOT)
     subprocess.check_call([sys.executable, "-c", code])
+
+
+def test_graft_entry_build_runs(kvc):
+    """__graft_entry__.build() — the driver's "does it build" check: make for the HIP library (gfx950 cross-compile) and
+    the oracle, import of the package, version and exports."""
+    import importlib
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
