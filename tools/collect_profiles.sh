@@ -10,6 +10,10 @@ cd /tmp && export TMPDIR=/tmp
 # 1. kernel trace + stats of the default bench command (batch mode, exact dot, torch_cpu ties)
 rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_under_rocprof.log 2>&1
 grep "kvc::\|^\"Name" /tmp/kt/*/*_kernel_stats.csv > $OUT/${TAG}_kernel_stats_c2_batch.csv
+# 1b. the same launches alone (tools/prof_driver.py makes nothing but the batched call): the per-kernel AVERAGE here is the
+#     duration of one 32-layer launch (the file above mixes them with bench.py's per-call warm-up launches)
+rm -rf /tmp/kt1b && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt1b -- python3 $R/tools/prof_driver.py c2 torch_cpu 10 batch > /dev/null 2>&1
+grep "kvc::\|^\"Name" /tmp/kt1b/*/*_kernel_stats.csv > $OUT/${TAG}_kernel_stats_c2_batch_launches_only.csv
 # 2. same, per-layer calls on one stream (what a strictly sequential caller sees)
 rm -rf /tmp/kt2 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --mode calls --streams 1 --no-graph > /dev/null 2>&1
 grep "kvc::\|^\"Name" /tmp/kt2/*/*_kernel_stats.csv > $OUT/${TAG}_kernel_stats_c2_calls_single_stream.csv
