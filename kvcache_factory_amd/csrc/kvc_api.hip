@@ -99,7 +99,9 @@ Layout carve(const kvc_params* p, int n_items = 1) {
         const size_t R = p->method == KVC_H2O ? L : W;     // query rows that score
         l.logits = off; off = align_up(off + heads * L * R * es, 256);
         l.pmax = off;   off = align_up(off + (p->method == KVC_H2O ? 0 : heads * (size_t)l.n_tiles * W * 4), 256);
-        l.psum = off;   off = align_up(off + (p->method == KVC_H2O ? 0 : heads * (size_t)l.n_chunks * W * 4), 256);
+        // H2O: column sums of every 256-row block (+ one slot for the leftover rows), fp32, columns padded to even
+        l.psum = off;   off = align_up(off + (p->method == KVC_H2O ? heads * (size_t)(l.n_chunks + 1) * ((n + 1) & ~(size_t)1) * 4
+                                                                   : heads * (size_t)l.n_chunks * W * 4), 256);
         l.rowmax = off; off = align_up(off + heads * R * 4, 256);
         l.rowsum = off; off = align_up(off + heads * R * 4, 256);
         l.scores = off; off = align_up(off + heads * n * es, 256);
@@ -144,6 +146,7 @@ int enqueue_scores(const kvc_params* p, const Layout& l, const Items& it, char* 
             h.S = w + l.logits;
             h.rowmax = reinterpret_cast<float*>(w + l.rowmax);
             h.rinv = reinterpret_cast<float*>(w + l.rowsum);
+            h.part = reinterpret_cast<float*>(w + l.psum);
             h.scores = it.scores[i];
             h.q_stride_b = p->q_stride_b; h.q_stride_h = p->q_stride_h; h.q_stride_l = p->q_stride_l;
             h.k_stride_b = p->k_stride_b; h.k_stride_h = p->k_stride_h; h.k_stride_l = p->k_stride_l;

@@ -10,7 +10,9 @@
 //   h2o_rowsum_kernel : softmax denominators in torch's own order (16 strided chains + xor butterfly 8,4,2,1 —
 //                       aten vec::reduce_all, 16 fp32 lanes): 4 rows per wave, 16 lanes per row.
 //   h2o_colsum_kernel : one thread per key column walks the L rows in order: p = round(exp_u20(s - m) * rinv),
-//                       accumulated in torch's cascade order (SumKernel multi_row_sum), rounded once.
+//                       accumulated in torch's cascade order (SumKernel multi_row_sum), rounded once.  Wide forms for
+//                       16-bit dtypes: two columns per thread, and (L >= 512) 256-row blocks in parallel combined in the
+//                       cascade's own order (h2o_colpart_kernel / h2o_colcomb_kernel).
 // MFMA-bound by construction (2*Hq*L*L*D flops at the f32-MFMA rate); a bf16-MFMA variant is the planned
 // follow-up and cannot be bit-exact with the oracle (tools/mfma_probe.hip).
 #include "kvc_common.h"
@@ -304,6 +306,70 @@ __global__ __launch_bounds__(256) void h2o_colsum_wide_kernel(const H2OArgs a) {
         (uint32_t)Dt<DT>::st(rnd<DT>(res.x)) | ((uint32_t)Dt<DT>::st(rnd<DT>(res.y)) << 16);
 }
 
+// Column sums split over the rows.  torch's cascade (SumKernel multi_row_sum, level step 16 for any L <= 2^19) is a tree:
+// 16 rows into a0, 16 such chunks into a1 (256 rows), 16 of those into a2, the rest into a3 — and every accumulator
+// restarts from zero after it is dumped.  So the sum of one 256-row block is independent of the others:
+//   h2o_colpart_kernel : (column pair, 256-row block) -> the block's a1 (and a0 of the rows beyond the last full chunk)
+//   h2o_colcomb_kernel : per column pair, the blocks combined in the cascade's own order: a2 over 16 blocks, a3 over
+//                        those, result ((a0 + a1) + a2) + a3.
+// 32x the parallelism of one thread walking all L rows (which ran at two waves per SIMD).
+template <int DT>
+__global__ __launch_bounds__(256) void h2o_colpart_kernel(const H2OArgs a) {
+    const int hb = blockIdx.y, g = blockIdx.z, L = a.q_len, n = L - a.window;
+    const int jcol = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (jcol >= n) return;
+    const int n_pad = (n + 1) & ~1, n_blk = (L + 255) / 256;
+    const int r0 = g * 256, r1 = r0 + 256 < L ? r0 + 256 : L, full = L - (L % 16);
+    const uint32_t* S = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.S) + ((int64_t)hb * L * L + jcol) * 2);
+    const float* m = a.rowmax + (int64_t)hb * L;
+    const float* ri = a.rinv + (int64_t)hb * L;
+    const int64_t pitch = L / 2;
+    f32x2 a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f};
+    auto row = [&](uint32_t w, int r) {
+        const float mr = m[r], rr = ri[r];
+        const f32x2 pr = exp_u20x2(widen2<DT>(w) - f32x2{mr, mr}) * f32x2{rr, rr};
+        a0 = a0 + f32x2{rnd<DT>(pr.x), rnd<DT>(pr.y)};
+        if (((r + 1) & 15) == 0 && r + 1 <= full) { a1 = a1 + a0; a0 = f32x2{0.0f, 0.0f}; }
+    };
+    constexpr int U = 8;
+    int r = r0;
+    for (; r + U <= r1; r += U) {
+        uint32_t w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = S[(int64_t)(r + u) * pitch];
+#pragma unroll
+        for (int u = 0; u < U; ++u) row(w[u], r + u);
+    }
+    for (; r < r1; ++r) row(S[(int64_t)r * pitch], r);
+    float* part = a.part + ((int64_t)hb * (n_blk + 1) + g) * n_pad + jcol;
+    part[0] = a1.x; part[1] = a1.y;
+    if (g == n_blk - 1) {                                   // rows beyond the last full chunk stay in a0
+        float* left = a.part + ((int64_t)hb * (n_blk + 1) + n_blk) * n_pad + jcol;
+        left[0] = a0.x; left[1] = a0.y;
+    }
+}
+template <int DT>
+__global__ __launch_bounds__(256) void h2o_colcomb_kernel(const H2OArgs a) {
+    const int hb = blockIdx.y, L = a.q_len, n = L - a.window;
+    const int jcol = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (jcol >= n) return;
+    const int n_pad = (n + 1) & ~1, n_blk = (L + 255) / 256, n_complete = L / 256;
+    const float* base = a.part + (int64_t)hb * (n_blk + 1) * n_pad + jcol;
+    f32x2 a2 = {0.0f, 0.0f}, a3 = {0.0f, 0.0f};
+    for (int g = 0; g < n_complete; ++g) {                  // a complete block's a1 is dumped into a2 at row 256 (g + 1)
+        const float2 p = *reinterpret_cast<const float2*>(base + (int64_t)g * n_pad);
+        a2 = a2 + f32x2{p.x, p.y};
+        if (((g + 1) & 15) == 0) { a3 = a3 + a2; a2 = f32x2{0.0f, 0.0f}; }
+    }
+    f32x2 a1 = {0.0f, 0.0f};
+    if (n_complete < n_blk) { const float2 p = *reinterpret_cast<const float2*>(base + (int64_t)n_complete * n_pad); a1 = f32x2{p.x, p.y}; }
+    const float2 l0 = *reinterpret_cast<const float2*>(base + (int64_t)n_blk * n_pad);
+    const f32x2 a0 = {l0.x, l0.y};
+    const f32x2 res = ((a0 + a1) + a2) + a3;
+    reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.scores) + ((int64_t)hb * n + jcol) * 2)[0] =
+        (uint32_t)Dt<DT>::st(rnd<DT>(res.x)) | ((uint32_t)Dt<DT>::st(rnd<DT>(res.y)) << 16);
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void h2o_colsum_kernel(const H2OArgs a) {
     typedef typename Dt<DT>::raw raw;
@@ -336,7 +402,13 @@ static int launch_h2o_t(const H2OArgs& a, hipStream_t st) {
     if constexpr (DT != KVC_FP32) {
         if (wide) {
             hipLaunchKernelGGL((h2o_rowsum_wide_kernel<DT>), dim3((unsigned)((L + 127) / 128), (unsigned)heads), dim3(256), 0, st, a);
-            hipLaunchKernelGGL((h2o_colsum_wide_kernel<DT>), dim3((unsigned)((n / 2 + 255) / 256), (unsigned)heads), dim3(256), 0, st, a);
+            if (L >= 512 && a.part) {
+                const unsigned n_blk = (unsigned)((L + 255) / 256);
+                hipLaunchKernelGGL((h2o_colpart_kernel<DT>), dim3((unsigned)((n / 2 + 255) / 256), (unsigned)heads, n_blk), dim3(256), 0, st, a);
+                hipLaunchKernelGGL((h2o_colcomb_kernel<DT>), dim3((unsigned)((n / 2 + 255) / 256), (unsigned)heads), dim3(256), 0, st, a);
+            } else {
+                hipLaunchKernelGGL((h2o_colsum_wide_kernel<DT>), dim3((unsigned)((n / 2 + 255) / 256), (unsigned)heads), dim3(256), 0, st, a);
+            }
         }
     }
     if (!wide) {

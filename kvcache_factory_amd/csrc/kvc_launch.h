@@ -43,6 +43,7 @@ struct H2OArgs {
     void* S;               // [bsz*Hq][L][L] dtype logits
     float* rowmax;         // [bsz*Hq][L]
     float* rinv;           // [bsz*Hq][L]
+    float* part;           // [bsz*Hq][n_blk + 1][n_pad] column sums of each 256-row block (+ the leftover rows), or null
     void* scores;          // [bsz*Hq][L-W] dtype
     int64_t q_stride_b, q_stride_h, q_stride_l;
     int64_t k_stride_b, k_stride_h, k_stride_l;
