@@ -501,10 +501,12 @@ struct WaveHeap9 {
         force_bit(len);
     }
     // __adjust_heap(first, t, len, value) for a node t of the top part (t <= 62), with its __push_heap.
+    template <bool TOP = false>
     __device__ __forceinline__ void adjust(int t, u64 At, int len, uint32_t value) {
         const u64 in_top = len >= 63 ? 0x7fffffffffffffffull : ((1ull << len) - 1);
-        const bool onp = lane == t || (((A >> t) & 1) && (((M ^ R) & A & ~At) == 0));
-        const u64 on_top = __ballot(onp) & in_top;
+        u64 on_top;
+        if constexpr (TOP) on_top = __ballot(((M ^ R) & A) == 0) & in_top;          // t == 0: lane 0 has no ancestors
+        else on_top = __ballot(lane == t || (((A >> t) & 1) && (((M ^ R) & A & ~At) == 0))) & in_top;
         // does the path leave the top part?  the on-path level-5 node (31..62) and its chosen level-6 child
         const u64 m5 = on_top & 0x7fffffff80000000ull;
         int j6 = -1;
@@ -575,7 +577,7 @@ __device__ __forceinline__ void partial_sort_wave9(const typename Dt<DT>::raw* s
                 pending &= pending - 1;
                 const uint32_t kk = __builtin_amdgcn_readlane(cur[j], src);
                 if (kk > root) {
-                    H.adjust(0, 0, k, N::make(kk, i0 + src));
+                    H.adjust<true>(0, 0, k, N::make(kk, i0 + src));
                     root = N::key(N::rdlane(H.top, 0));
                 }
             }
@@ -589,7 +591,7 @@ __device__ __forceinline__ void partial_sort_wave9(const typename Dt<DT>::raw* s
         const uint32_t value = H.node(last), topv = N::rdlane(H.top, 0);
         if (lane == 0) res[last] = topv;
         H.force_bit(last);
-        H.adjust(0, 0, last, value);
+        H.adjust<true>(0, 0, last, value);
     }
     if (lane == 0) res[0] = H.top;
     __syncthreads();
