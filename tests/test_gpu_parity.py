@@ -567,3 +567,35 @@ def test_random_shapes_h2o_and_streaming_vs_oracle(kvc, oracle, gpu_device, case
     ks, vs = kvc.compress(kvc.STREAMINGLLM, None, k, v, W, keep, n_q_heads=hq)
     ko_, vo_, _ = oracle.streaming(k.cpu(), v.cpu(), W, keep, hq)
     assert torch.equal(G.bits(ks.cpu()), G.bits(ko_)) and torch.equal(G.bits(vs.cpu()), G.bits(vo_))
+
+
+def test_patched_mistral_on_gpu(kvc, gpu_device):
+    """replace_mistral("snapkv") on a small bf16 Mistral (32 q / 8 kv heads of 128, sliding window as in
+    Mistral-7B-Instruct-v0.2: none) on the GPU: layer-batched compression equals one update_kv per layer — cache bytes,
+    true lengths, generated tokens."""
+    from transformers import MistralConfig, MistralForCausalLM
+    from kvcache_factory_amd import monkeypatch as mp, pyramidkv_utils as pu
+    cfg = MistralConfig(hidden_size=4096, intermediate_size=256, num_hidden_layers=3, num_attention_heads=32,
+                        num_key_value_heads=8, head_dim=128, vocab_size=256, max_position_embeddings=4096,
+                        sliding_window=None, attn_implementation="sdpa")
+    torch.manual_seed(1)
+    model = MistralForCausalLM(cfg).to(torch.bfloat16).to(gpu_device).eval()
+    L, cap, W = 600, 72, 8
+    ids = torch.randint(0, 256, (1, L), generator=torch.Generator().manual_seed(6)).to(gpu_device)
+    old_flag, outs = pu.BATCH_LAYERS, {}
+    try:
+        mp.replace_mistral("snapkv")
+        for layer in model.model.layers:
+            for name, val in (("window_size", W), ("max_capacity_prompt", cap), ("kernel_size", 7), ("pooling", "maxpool")):
+                setattr(layer.self_attn.config, name, val)
+        for flag in (True, False):
+            pu.BATCH_LAYERS = flag
+            with torch.no_grad():
+                outs[flag] = model.generate(ids, max_new_tokens=3, do_sample=False, use_cache=True, return_dict_in_generate=True)
+    finally:
+        pu.BATCH_LAYERS = old_flag
+        mp.replace_mistral("fullkv")
+    assert torch.equal(outs[True].sequences, outs[False].sequences)
+    for la, lb in zip(outs[True].past_key_values.layers, outs[False].past_key_values.layers):
+        assert la.get_seq_length() == lb.get_seq_length() == L + 2 and la.keys.shape[2] == cap + 2
+        assert torch.equal(la.keys, lb.keys) and torch.equal(la.values, lb.values)
