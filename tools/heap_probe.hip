@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
             std::vector<unsigned long long> t(grid);
             (void)hipMemcpy(t.data(), dt, grid * 8, hipMemcpyDeviceToHost);
             unsigned long long mx = 0, sum = 0; for (auto v : t) { mx = v > mx ? v : mx; sum += v; }
-            printf("grid %4d: kernel %.1f us; s_memtime ticks per wave: mean %.0f max %llu (100 MHz ticks -> us: mean %.1f)\n", grid, ms * 1000, (double)sum / grid, mx, (double)sum / grid / 100.0);
+            printf("grid %4d: kernel %.1f us; shader cycles per wave (s_memtime): mean %.0f max %llu\n", grid, ms * 1000, (double)sum / grid, mx);
         }
     }
     return 0;
