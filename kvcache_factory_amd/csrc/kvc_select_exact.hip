@@ -317,7 +317,55 @@ struct WaveSel {
         __syncthreads();
         return lnext < rlast ? lnext : rlast;
     }
+    // __unguarded_partition_pivot of a range of at most 64 elements (most calls of the sort phase), one element per lane
+    // in registers: median-of-three and its swap by readlane, the two stopper sets as ballots, the pairing by popcounts
+    // (left stopper i of rank t is swapped iff at least t right stoppers lie above it), partners through two 65-entry
+    // LDS tables and one ds_bpermute.  Same moves as partition(); ~3 LDS round trips instead of ~10.  Kept out of line:
+    // inlined, its registers slowed the long scans of partition() by 20 %.
+    __device__ __forceinline__ static u64 rd64(u64 v, int l) {
+        const uint32_t a = __builtin_amdgcn_readlane((uint32_t)v, l), b = __builtin_amdgcn_readlane((uint32_t)(v >> 32), l);
+        return ((u64)b << 32) | a;
+    }
+    __device__ __noinline__ int partition_pivot_small(int first, int last) {
+        const int m = last - first;                                       // 4 .. 64
+        u64 x = lane < m ? arr[first + lane] : 0ull;
+        // __move_median_to_first(first, first + 1, mid, last - 1)
+        const int ia = 1, ib = m / 2, ic = m - 1;
+        const u64 va = rd64(x, ia), vb = rd64(x, ib), vc = rd64(x, ic);
+        int sw;
+        if (comp(va, vb)) sw = comp(vb, vc) ? ib : (comp(va, vc) ? ic : ia);
+        else sw = comp(va, vc) ? ia : (comp(vb, vc) ? ic : ib);
+        const u64 v0 = rd64(x, 0), vs = rd64(x, sw);
+        x = lane == 0 ? vs : (lane == sw ? v0 : x);
+        // __unguarded_partition(first + 1, last, pivot = first)
+        const uint32_t pk = key(vs), kx = key(x);
+        const bool in = lane >= 1 && lane < m;
+        const u64 SL = __ballot(in && !(kx > pk)), SR = __ballot(in && !(pk > kx));
+        const u64 below_incl = lane >= 63 ? ~0ull : ((2ull << lane) - 1), above = lane >= 63 ? 0ull : (~0ull << (lane + 1));
+        const bool isl = (SL >> lane) & 1, isr = (SR >> lane) & 1;
+        const int t = __builtin_popcountll(SL & below_incl);              // rank among left stoppers, 1-based, ascending
+        const int u = __builtin_popcountll(SR & (above | (1ull << lane)));  // rank among right stoppers, 1-based, descending
+        const bool swl = isl && __builtin_popcountll(SR & above) >= t;
+        const bool swr = isr && __builtin_popcountll(SL & (below_incl >> 1)) >= u;   // left stoppers strictly below
+        const int T = __builtin_popcountll(__ballot(swl));
+        int* const tl = small;                                            // positions by rank (LDS, 2 x 65 ints)
+        int* const tr = small + 65;
+        if (isl) tl[t] = lane;
+        if (isr) tr[u] = lane;
+        __syncthreads();
+        const int partner = swl ? tr[t] : (swr ? tl[u] : lane);
+        const int NL = __builtin_popcountll(SL);
+        const int lnext = T < NL ? uni(tl[T + 1]) : 0x7fffffff;
+        const int rlast = T > 0 ? uni(tr[T]) : 0x7fffffff;
+        const uint32_t plo = (uint32_t)__builtin_amdgcn_ds_bpermute(partner << 2, (int)(uint32_t)x);
+        const uint32_t phi = (uint32_t)__builtin_amdgcn_ds_bpermute(partner << 2, (int)(uint32_t)(x >> 32));
+        x = ((u64)phi << 32) | plo;
+        if (lane < m) arr[first + lane] = x;
+        __syncthreads();
+        return first + (lnext < rlast ? lnext : rlast);
+    }
     __device__ int partition_pivot(int first, int last) {                 // __unguarded_partition_pivot
+        if (small != nullptr && last - first <= 64) return partition_pivot_small(first, last);
         const int mid = first + (last - first) / 2;
         Arr A{arr};
         if (lane == 0) move_median_to_first_(A, first, first + 1, mid, last - 1);
