@@ -390,12 +390,13 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
                 }
             }
         };
-        // A tile is "plain" when none of those cases applies: its epilogue is then branch-free and rides, a pair of
-        // accumulator elements at a time, between the MFMA steps of the NEXT tile.
+        // A tile is "plain" when none of those cases applies: its epilogue is then branch-free, a pair of accumulator
+        // elements at a time on the packed-fp32 ALU.  (Riding it between the MFMA steps of the next tile, as earlier
+        // versions did, buys nothing: the f32 MFMA and the VALU do not overlap on gfx950.)
         const bool rows_plain = (W % 4) == 0 && (mt + 1) * 32 <= rows;
-        // Plain epilogue of accumulator elements e0, e0+1 of the pending tile (rows i0+e0%4, +1 of register group e0/4).
+        // Plain epilogue of accumulator elements e0, e0+1 (rows i0+e0%4, +1 of register group e0/4).
         uint32_t pkw[2];                                       // packed words of the current register group
-        auto plain_pair = [&](const f32x16& pend, int e0, uint32_t pkeyoff) {
+        auto plain_pair = [&](const f32x16& pend, int e0, uint32_t pkeyoff) {     // pend: the tile's accumulators
             if constexpr (DT == KVC_FP32) {
                 const float v0 = ScaleDiv<D>::apply_in_guard(pend[e0], sqrt_d), v1 = ScaleDiv<D>::apply_in_guard(pend[e0 + 1], sqrt_d);
                 rm[e0] = v0 > rm[e0] ? v0 : rm[e0];
@@ -412,9 +413,6 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
                 if ((e0 & 3) == 2) *reinterpret_cast<uint2*>(lg + (soff[e0 >> 2] + pkeyoff)) = make_uint2(pkw[0], pkw[1]);
             }
         };
-        constexpr int EPC = 16 / NSTEP;       // accumulator elements of the previous tile per MFMA step (1, 2 or 4)
-        f32x16 pend = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        int ptile = -1;                        // tile whose (plain) epilogue is still pending
         for (; tile < n_t; tile += n_waves) {
             const int next = tile + n_waves;
             if (next < n_t) issue(next, st);                  // in flight during the MFMAs below
@@ -422,15 +420,7 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
             KVC_STAMP(2);
             // ---- 32 rows x 32 keys, chain over d = 0..D-1 in order ----
             f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            const uint32_t pkeyoff = (uint32_t)(ptile * 32 + j) * (uint32_t)(W * ES);
-            // the pairs of the pending tile that ride behind MFMA step ic
-            auto ride = [&](auto ic_) {
-                constexpr int ic = decltype(ic_)::value;
-#pragma unroll
-                for (int pr = (ic * EPC) / 2; pr < ((ic + 1) * EPC) / 2; ++pr) plain_pair(pend, 2 * pr, pkeyoff);
-            };
-            auto chain = [&](auto withp_) {
-                constexpr bool withp = decltype(withp_)::value;
+            auto chain = [&]() {
                 if constexpr (ASM_B) {
                     // operands by hand-issued LDS reads, one step ahead of the MFMAs that consume them:
                     //   A: 4 fragment values (ds_read_b128, chunk-major image);  B: 4 x bf16 -> fp32 in the load itself.
@@ -451,7 +441,6 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
 #pragma unroll
                         for (int s4 = 0; s4 < 4; ++s4)
                             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[s4], u2f(Bc[s4]), acc, 0, 0, 0);
-                        if constexpr (withp) ride(ic_);
                     });
                     asm volatile("" ::: "memory");            // ... and the next tile's ds_writes stay below them
                 } else {
@@ -472,18 +461,16 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
                                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc * PAIRS + sp], pick<DT>(kv, sp, psel), acc, 0, 0, 0);
                             }
                         }
-                        if constexpr (withp) ride(ic_);
                     });
                 }
             };
-            if (ptile >= 0) { chain(std::true_type{}); ptile = -1; }
-            else chain(std::false_type{});
+            chain();
             asm volatile("" :: "v"(acc[0]), "v"(acc[15]));
             // the tile's LDS reads are all issued (the LDS serves a wave in order): the next tile may overwrite the single
             // buffer now, so its ds_writes overlap the VALU work that follows
             if (next < n_t) commit(st);
             KVC_STAMP(3);
-            bool plain = rows_plain && tile * 32 + 32 <= L - W && next < n_t;
+            bool plain = rows_plain && tile * 32 + 32 <= L - W;
             if (plain) {
                 // the branch-free scaling needs every |value| of the tile inside [2^-98, 2^126] (rounding to dtype moves a
                 // value by < 1 %, so this keeps the rounded value inside the proven [2^-100, inf) guard); a zero logit, an
@@ -497,8 +484,13 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
                 }
                 plain = !__any(!(amin >= 0x0e800000u && amax <= 0x7e800000u));
             }
-            if (plain) { pend = acc; ptile = tile; }           // finished under the next tile's MFMAs
-            else epilogue_general(acc, tile);
+            if (plain) {                                        // branch-free epilogue, two accumulator elements at a time
+                const uint32_t keyoff = (uint32_t)(tile * 32 + j) * (uint32_t)(W * ES);
+#pragma unroll
+                for (int pr = 0; pr < 8; ++pr) plain_pair(acc, 2 * pr, keyoff);
+            } else {
+                epilogue_general(acc, tile);
+            }
             KVC_STAMP(5);
         }
         // ---- block-level maximum per row -> pmax[hq][blockIdx.x][w] ----
