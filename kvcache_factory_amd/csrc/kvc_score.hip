@@ -406,8 +406,10 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
                 f32x2 x = {pend[e0], pend[e0 + 1]}, back;
                 (void)pack2<DT>(x, back);                                         // first rounding
                 const f32x2 q = scale2_in_guard<D>(back, sqrt_d);                 // second: after the scaling
-                rm[e0] = __builtin_fmaxf(rm[e0], q.x);                            // (maximum before rounding: monotonic)
-                rm[e0 + 1] = __builtin_fmaxf(rm[e0 + 1], q.y);
+                // (maximum before rounding: monotonic.)  One v_max_f32 each, spelled out: fmaxf() makes the compiler
+                // re-canonicalise all 16 running maxima at the top of every tile
+                asm("v_max_f32 %0, %1, %2" : "=v"(rm[e0]) : "v"(rm[e0]), "v"(q.x));
+                asm("v_max_f32 %0, %1, %2" : "=v"(rm[e0 + 1]) : "v"(rm[e0 + 1]), "v"(q.y));
                 f32x2 unused;
                 pkw[(e0 >> 1) & 1] = pack2<DT>(q, unused);
                 if ((e0 & 3) == 2) *reinterpret_cast<uint2*>(lg + (soff[e0 >> 2] + pkeyoff)) = make_uint2(pkw[0], pkw[1]);
