@@ -159,10 +159,15 @@ template <int DT> __device__ __forceinline__ uint32_t pack2(f32x2 v, f32x2& back
 template <int D> __device__ __forceinline__ f32x2 scale2_in_guard(f32x2 x, float c);   // ScaleDiv<D>::apply_in_guard x 2
 template <> __device__ __forceinline__ f32x2 scale2_in_guard<64>(f32x2 x, float) { return x * (f32x2)0.125f; }
 template <> __device__ __forceinline__ f32x2 scale2_in_guard<128>(f32x2 x, float c) {
-    const f32x2 rc = u2f(0x3db504f3u);
-    const f32x2 q0 = x * rc;
-    const f32x2 r = __builtin_elementwise_fma(-q0, (f32x2)c, x);
-    return __builtin_elementwise_fma(r, rc, q0);
+    // three packed-fp32 instructions with the two constants broadcast from SGPR pairs (the compiler scalarises the
+    // f32x2 form into six when the constants live in SGPRs)
+    const uint32_t rcb = 0x3db504f3u, cb = f2u(c);
+    const unsigned long long rc2 = ((unsigned long long)rcb << 32) | rcb, c2 = ((unsigned long long)cb << 32) | cb;
+    f32x2 q0, r, q;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(q0) : "v"(x), "s"(rc2));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(q0), "s"(c2), "v"(x));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(q) : "v"(r), "s"(rc2), "v"(q0));
+    return q;
 }
 
 // ---------------------------------------------------------------------------------------------
