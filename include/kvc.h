@@ -16,7 +16,8 @@
  *   - the library never allocates device memory, never synchronises the stream and never throws:
  *     all kernels are enqueued on `hip_stream` (a hipStream_t, NULL = default stream);
  *   - tensors are indexed [b][h][l][d] with d contiguous and element strides given in the params;
- *   - outputs are dense: k_out/v_out [bsz][n_q_heads][k+window][head_dim] in the input dtype,
+ *   - outputs: k_out/v_out [bsz][n_q_heads][k+window][head_dim] in the input dtype, dense or with a caller-chosen
+ *     head stride (kvc_params.out_stride_h: a decode cache with spare rows per head),
  *     idx_out [bsz][n_q_heads][k] int64 (value-descending order, like torch.topk), scores_out
  *     [bsz][n_q_heads][q_len-window] in the input dtype (the pooled scores of :328-333);
  *   - return value 0 on success, negative kvc_status otherwise; kvc_last_error() gives the text.
