@@ -281,3 +281,31 @@ def test_decode_appends_in_place(cpu_backend):
         if step < 3:
             assert layer._kbuf.data_ptr() == ptr                      # spare rows: same storage
     assert layer._kbuf.data_ptr() != ptr and layer._kbuf.shape[2] >= 18  # grew by doubling
+
+
+def test_prefill_batch_groups_by_layout(cpu_backend, monkeypatch):
+    """PrefillBatch.flush issues one compress_batch per group of entries that share a layout (shape, strides, dtype, window,
+    pooling ...); sinks receive their own results in the order the entries were added; H2O and pass-through are refused."""
+    calls = []
+
+    def spy(method_, qs, ks, vs, window, keeps, *a, **kw):
+        calls.append((len(ks), tuple(ks[0].shape), list(keeps)))
+        return oracle_compress_batch(method_, qs, ks, vs, window, keeps, *a, **kw)
+    monkeypatch.setattr(_kvc, "compress_batch", spy)
+    g = torch.Generator().manual_seed(11)
+    mk = lambda L: (torch.randn(1, 2, L, 64, generator=g), torch.randn(1, 4, L, 64, generator=g), torch.randn(1, 2, L, 64, generator=g))   # noqa: E731
+    pb, got = pu.PrefillBatch(), {}
+    cl = pu.SnapKVCluster(window_size=4, max_capacity_prompt=20, kernel_size=3, pooling="maxpool")
+    for name, L in (("a", 64), ("b", 96), ("c", 64)):
+        k, q, v = mk(L)
+        assert pb.add(cl, k, q, v, lambda kc, vc, name=name: got.__setitem__(name, (kc, vc)), tag=name)
+        ko, vo = oracle_compress(_kvc.SNAPKV, q, k, v, 4, 16, 3, "maxpool")
+        got[name + "_want"] = (ko, vo)
+    k, q, v = mk(10)
+    assert not pb.add(cl, k, q, v, None)                                         # q_len < cap: pass-through is the caller's
+    assert not pb.add(pu.H2OKVCluster(window_size=4, max_capacity_prompt=20), *[t for t in (mk(64)[0], mk(64)[1], mk(64)[2])], None)
+    assert len(pb) == 3 and pb.holds("b")
+    pb.flush()
+    assert len(pb) == 0 and sorted(c[0] for c in calls) == [1, 2]               # L = 64 twice in one call, L = 96 alone
+    for name in "abc":
+        assert torch.equal(got[name][0], got[name + "_want"][0]) and torch.equal(got[name][1], got[name + "_want"][1])
