@@ -17,6 +17,7 @@
 // follow-up and cannot be bit-exact with the oracle (tools/mfma_probe.hip).
 #include "kvc_common.h"
 #include "kvc_launch.h"
+#include "kvc_ldsasm.h"
 
 namespace kvc {
 
@@ -57,11 +58,12 @@ __global__ __launch_bounds__(256) void h2o_logits_kernel(const H2OArgs a) {
     typedef typename Dt<DT>::raw raw;
     constexpr int ES = Dt<DT>::esize;
     constexpr int ROWB = D * ES, CH = ROWB / 16, PAIRS = 8 / ES, SWZ = CH < 16 ? CH - 1 : 15, STG = CH / 2;
-    // (Operands widened by ds_read_u16_d16_hi as in kvc_score.hip were tried here and REJECTED: with this kernel's
-    // double-buffered tiles the hand-issued loads produced rare, run-to-run different 1-ulp logit errors at L = 8000
-    // (about one logit in 10^6; cause not found).  The B operand keeps its v_perm widening.)
-    constexpr bool ASM_B = false;
-    constexpr int ROWP = ROWB;
+    // bf16: the B operand is widened by the LDS load itself (ds_read_u16_d16_hi, kvc_ldsasm.h) as in kvc_score.hip — one
+    // VALU instruction (v_perm) less per MFMA on a pipe that does not overlap the f32 MFMA.  Round 1 rejected this here
+    // for "rare, run-to-run different" logit errors; the cause was a destination allocated onto the address register
+    // of a multi-load asm statement (kvc_ldsasm.h (1)), fixed by early-clobber outputs and audited per build.
+    constexpr bool ASM_B = (DT == KVC_BF16);
+    constexpr int ROWP = ASM_B ? ROWB + 4 : ROWB;          // odd dword pitch: the 32 keys of a read sit in 32 banks
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
     const int hb = blockIdx.y, b = hb / a.n_q_heads, h = hb % a.n_q_heads, g = h / a.group;
@@ -121,7 +123,21 @@ __global__ __launch_bounds__(256) void h2o_logits_kernel(const H2OArgs a) {
         const char* krow = buf + cur * (32 * ROWP) + j * ROWP;
         const int key = tile * 32 + j;
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        {
+        if constexpr (ASM_B) {
+            // operands one step ahead of the MFMAs that consume them (4 LDS reads per step, kvc_ldsasm.h)
+            const uint32_t krow_a = lds_addr(krow) + 2 * kh;
+            uint32_t B0[4], B1[4];
+            ld_b_step<0>(B0, krow_a);
+            static_for<0, D / 8>([&](auto ic_) {
+                constexpr int ic = decltype(ic_)::value;
+                uint32_t (&Bc)[4] = (ic & 1) ? B1 : B0;
+                if constexpr (ic + 1 < D / 8) { ld_b_step<ic + 1>((ic & 1) ? B0 : B1, krow_a); wait_b_step<4>(Bc); }
+                else wait_b_step<0>(Bc);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[ic * 4 + s4], u2f(Bc[s4]), acc, 0, 0, 0);
+            });
+        } else {
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 const uint4 kv = *reinterpret_cast<const uint4*>(krow + ((c ^ (j & SWZ)) * 16));
@@ -391,7 +407,7 @@ __global__ __launch_bounds__(256) void h2o_colsum_kernel(const H2OArgs a) {
 template <int DT, int D>
 static int launch_h2o_t(const H2OArgs& a, hipStream_t st) {
     constexpr int ES = Dt<DT>::esize;
-    const size_t lds = (size_t)4 * 2 * 32 * D * ES;
+    const size_t lds = (size_t)4 * 2 * 32 * (D * ES + (DT == KVC_BF16 ? 4 : 0));   // 4 waves x 2 tile buffers (ROWP pitch)
     static LdsCache lds_cache = {};
     if (ensure_lds(reinterpret_cast<const void*>(&h2o_logits_kernel<DT, D>), lds, lds_cache) != 0) return KVC_ERR_HIP;
     const int L = a.q_len, n = L - a.window, heads = a.bsz * a.n_q_heads;

@@ -19,6 +19,7 @@
 
 #include "kvc_common.h"
 #include "kvc_launch.h"
+#include "kvc_ldsasm.h"
 
 namespace kvc {
 
@@ -116,33 +117,8 @@ template <int DT> __device__ __forceinline__ f32x16 mfma16(const uint4& av, cons
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, av), __builtin_bit_cast(h16x8, bv), acc, 0, 0, 0);
 }
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N)
-template <int I0, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I0 < N) { f(std::integral_constant<int, I0>{}); static_for<I0 + 1, N>(f); }
-}
-// MFMA step STI of the exact bf16 scan: issue the LDS reads of its operands (not tracked by the compiler: pair with
-// wait_step before use).  A: chunk STI of the lane's fp32 fragment; B: bf16 elements 8*STI + 2s + kh, s = 0..3, widened by
-// the load (ds_read_u16_d16_hi clears the low half on gfx950: tools/d16_probe.hip).
-template <int STI> __device__ __forceinline__ void ld_step(f32x4& A, uint32_t (&B)[4], uint32_t arow_a, uint32_t krow_a) {
-    asm volatile("ds_read_b128 %0, %5 offset:%7\n\t"
-                 "ds_read_u16_d16_hi %1, %6 offset:%8\n\t"
-                 "ds_read_u16_d16_hi %2, %6 offset:%9\n\t"
-                 "ds_read_u16_d16_hi %3, %6 offset:%10\n\t"
-                 "ds_read_u16_d16_hi %4, %6 offset:%11"
-                 : "=v"(A), "=v"(B[0]), "=v"(B[1]), "=v"(B[2]), "=v"(B[3])
-                 : "v"(arow_a), "v"(krow_a), "n"(STI * 1024), "n"(STI * 16), "n"(STI * 16 + 4), "n"(STI * 16 + 8), "n"(STI * 16 + 12));
-}
-template <int N> __device__ __forceinline__ void wait_step(f32x4& A, uint32_t (&B)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(A), "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]) : "n"(N));
-}
-
-
-__device__ __forceinline__ uint32_t lds_addr(const void* p) {       // byte address inside the workgroup's LDS
-    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
-}
 // Two values rounded to the storage dtype: the packed bits (element 0 in the low half) and the rounded values in fp32.
 template <int DT> __device__ __forceinline__ uint32_t pack2(f32x2 v, f32x2& back) {
     if constexpr (DT == KVC_BF16) {
