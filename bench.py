@@ -279,7 +279,7 @@ def cpu_baseline(cfg, budget_s=12.0, dev=None):
             par = {}
             for tie, otie in (("canonical", O.TIES_CANON), ("torch_cpu", O.TIES_TORCH)):
                 ko, vo, idx, sc = O.compress(q, k, v, cfg["W"], n_keep, cfg["kernel"], cfg["pooling"], dot_mode=O.DOT_CHAIN,
-                                             sum_mode=O.SUM_KVC, tie_mode=otie, n_threads=threads)
+                                             sum_mode=O.SUM_TORCH16, tie_mode=otie, n_threads=threads)
                 g = _kvc.compress(METHODS[cfg["method"]], qd, kd, vd, cfg["W"], n_keep, cfg["kernel"], cfg["pooling"], tie,
                                   return_indices=True, return_scores=True)
                 gi, gs = g[2][0].cpu(), g[3][0].cpu()

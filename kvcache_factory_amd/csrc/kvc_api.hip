@@ -100,8 +100,7 @@ Layout carve(const kvc_params* p, int n_items = 1) {
         l.logits = off; off = align_up(off + heads * L * R * es, 256);
         l.pmax = off;   off = align_up(off + (p->method == KVC_H2O ? 0 : heads * (size_t)l.n_tiles * W * 4), 256);
         // H2O: column sums of every 256-row block (+ one slot for the leftover rows), fp32, columns padded to even
-        l.psum = off;   off = align_up(off + (p->method == KVC_H2O ? heads * (size_t)(l.n_chunks + 1) * ((n + 1) & ~(size_t)1) * 4
-                                                                   : heads * (size_t)l.n_chunks * W * 4), 256);
+        l.psum = off;   off = align_up(off + (p->method == KVC_H2O ? heads * (size_t)(l.n_chunks + 1) * ((n + 1) & ~(size_t)1) * 4 : 0), 256);
         l.rowmax = off; off = align_up(off + heads * R * 4, 256);
         l.rowsum = off; off = align_up(off + heads * R * 4, 256);
         l.scores = off; off = align_up(off + heads * n * es, 256);
@@ -164,13 +163,13 @@ int enqueue_scores(const kvc_params* p, const Layout& l, const Items& it, char* 
     a.n_items = it.n;
     a.ws = ws; a.ws_item_stride = (int64_t)l.total;
     a.off_logits = (int64_t)l.logits; a.off_pmax = (int64_t)l.pmax;
-    a.off_psum = (int64_t)l.psum; a.off_rowmax = (int64_t)l.rowmax; a.off_rowsum = (int64_t)l.rowsum;
+    a.off_rowmax = (int64_t)l.rowmax; a.off_rowsum = (int64_t)l.rowsum;
     a.q_stride_b = p->q_stride_b; a.q_stride_h = p->q_stride_h; a.q_stride_l = p->q_stride_l;
     a.k_stride_b = p->k_stride_b; a.k_stride_h = p->k_stride_h; a.k_stride_l = p->k_stride_l;
     a.bsz = p->bsz; a.n_q_heads = p->n_q_heads; a.n_kv_heads = p->n_kv_heads;
     a.group = p->n_q_heads / p->n_kv_heads;
     a.q_len = p->q_len; a.window = p->window;
-    a.n_tiles = l.n_tiles; a.n_chunks = l.n_chunks;
+    a.n_tiles = l.n_tiles;
     a.kernel_size = p->kernel_size; a.pooling = p->pooling;
     a.stage_mask = p->debug_stage_mask;
     a.fast_dot = (p->dot_mode == KVC_DOT_MFMA16 && p->dtype != KVC_FP32) ? 1 : 0;

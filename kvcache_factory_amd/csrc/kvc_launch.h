@@ -14,7 +14,7 @@ struct IntTable { int v[KVC_MAX_ITEMS]; };
 
 struct ScoreView {         // one item's pointers, resolved at kernel entry
     const void* q; const void* k;
-    void* logits; float* pmax; float* psum; float* rowmax; float* rowsum; void* scores;
+    void* logits; float* pmax; float* rowmax; float* rowsum; void* scores;
 };
 
 struct ScoreArgs {
@@ -24,14 +24,13 @@ struct ScoreArgs {
     // byte offsets inside an item's workspace:
     int64_t off_logits;    // [bsz*Hq][L][W] dtype
     int64_t off_pmax;      // [bsz*Hq][n_tiles][W] fp32
-    int64_t off_psum;      // [bsz*Hq][n_chunks][W] fp32
     int64_t off_rowmax;    // [bsz*Hq][W] fp32
     int64_t off_rowsum;    // [bsz*Hq][W] fp32
     int n_items;
     int64_t q_stride_b, q_stride_h, q_stride_l;
     int64_t k_stride_b, k_stride_h, k_stride_l;
     int bsz, n_q_heads, n_kv_heads, group, q_len, window;
-    int n_tiles, n_chunks, kernel_size, pooling;
+    int n_tiles, kernel_size, pooling;
     int fast_dot;          // 1: packed bf16/fp16 MFMA scan (tolerance mode), 0: exact f32 fmaf-chain MFMA
     int stage_mask;        // bits 0-2: 0 = all, else bit0 logits, bit1 rowsum, bit2 pool (profiling aid); bit3 / bit4: force the split / fused softmax path
     float sqrt_d;

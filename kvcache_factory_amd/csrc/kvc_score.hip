@@ -31,7 +31,6 @@ __device__ __forceinline__ ScoreView view_of(const ScoreArgs& a, int item) {
     v.q = a.q.p[item]; v.k = a.k.p[item]; v.scores = const_cast<void*>(a.scores.p[item]);
     v.logits = w + a.off_logits;
     v.pmax = reinterpret_cast<float*>(w + a.off_pmax);
-    v.psum = reinterpret_cast<float*>(w + a.off_psum);
     v.rowmax = reinterpret_cast<float*>(w + a.off_rowmax);
     v.rowsum = reinterpret_cast<float*>(w + a.off_rowsum);
     return v;
@@ -549,49 +548,123 @@ __device__ __forceinline__ void load_logits(const typename Dt<DT>::raw* src, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// rowsum_kernel: grid = (ceil(L/256), bsz*n_q_heads), block = 256, one key per thread.
-// psum[hb][chunk][w] = fixed-order sum over the chunk's keys of exp_u20(x[key][w] - max[w]).
+// Softmax denominators in torch's own order (aten vec::reduce_all on 16 fp32 lanes, the order of softmax's row sum on
+// the reference's AVX-512 host — oracle: sum_torch16): chain l, l = 0..15, adds the exponentials of keys l, l+16, l+32, ...
+// one after the other; the 16 chains are folded by an xor butterfly 8, 4, 2, 1.  (L < 16: one plain left-to-right sum.)
+// A chain is strictly serial over the whole row, so one workgroup owns a head: its 1024 threads compute the
+// exponentials of 1024 consecutive keys, stage them in LDS, and thread c < 16 * W — row c / 16, chain c % 16 — adds its
+// 64 terms of the stage in key order.  Two stage buffers: one barrier per 1024 keys.
+// With it the C5 fixtures (Mistral 32k -> 2048) select the reference's indices in 32 of 32 heads (round 1's own
+// 256-key-chunk order: 31 of 32; 126 -> 20 of 1 023 744 pooled scores off the reference).
+// ---------------------------------------------------------------------------------------------
+constexpr int SP_THREADS = 1024;
+constexpr int EPITCH = SP_THREADS + 16;                      // stage row pitch (floats): rows 16 banks apart
+constexpr int ESTAGE_ROWS = 8;                               // rows staged at a time
+constexpr int ESTAGE = ESTAGE_ROWS * EPITCH;                 // floats per stage buffer
+
+// acc += the terms of chain `cl` inside the stage that holds keys [base, base + 1024) of one row: 64 dependent adds, their
+// operands fetched eight at a time one batch ahead (the adds are the serial part of the whole softmax).
+__device__ __forceinline__ float chain16_add(float acc, const float* row /* stage row + cl */, int base, int cl, int L) {
+    const int cnt = (L - base - cl + 15) >> 4;               // keys base + cl + 16 i < L
+    if (cnt >= 64) {
+        float va[8], vb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) va[i] = row[16 * i];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            float (&cur)[8] = (b & 1) ? vb : va;
+            float (&nxt)[8] = (b & 1) ? va : vb;
+            if (b + 1 < 8) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) nxt[i] = row[16 * (8 * (b + 1) + i)];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc = acc + cur[i];
+        }
+    } else {
+        for (int i = 0; i < cnt; ++i) acc = acc + row[16 * i];
+    }
+    return acc;
+}
+// After the last stage: fold the 16 chains of each row; lanes with cl == 0 hold the row sum.
+__device__ __forceinline__ float chain16_fold(float acc) {
+    acc = acc + xor_lane<8>(acc);
+    acc = acc + xor_lane<4>(acc);
+    acc = acc + xor_lane<2>(acc);
+    acc = acc + xor_lane<1>(acc);
+    return acc;
+}
+
+// Row sums of one head.  E(it, w) -> exponential of key it * 1024 + tid, row w (0 for keys >= L).  Returns, in the threads
+// c = 16 w (w < W), the sum of row w.  stage: 2 * ESTAGE floats of LDS.  All 1024 threads must call it.
+template <class EF>
+__device__ __forceinline__ float torch16_rowsums(EF&& E, int L, int W, float* stage) {
+    const int tid = threadIdx.x;
+    const int cw = tid >> 4, cl = tid & 15;
+    const int iters = (L + SP_THREADS - 1) / SP_THREADS;
+    const int groups = (W + ESTAGE_ROWS - 1) / ESTAGE_ROWS;
+    float acc = 0.0f;                                        // 0 + x == x: the chain starts with its first term
+    int fill = 0;
+    if (L < 16) {                                            // vec::reduce_all's scalar path: one sum, left to right
+        for (int g = 0; g < groups; ++g) {
+            float* buf = stage + (fill & 1) * ESTAGE;
+            for (int r = 0; r < ESTAGE_ROWS; ++r) if (g * ESTAGE_ROWS + r < W) buf[r * EPITCH + tid] = E(0, g * ESTAGE_ROWS + r);
+            __syncthreads();
+            if (cl == 0 && (cw / ESTAGE_ROWS) == g && cw < W)
+                for (int k = 0; k < L; ++k) acc = acc + buf[(cw % ESTAGE_ROWS) * EPITCH + k];
+            ++fill;
+        }
+        return acc;
+    }
+    for (int it = 0; it < iters; ++it) {
+        for (int g = 0; g < groups; ++g) {
+            float* buf = stage + (fill & 1) * ESTAGE;
+#pragma unroll
+            for (int r = 0; r < ESTAGE_ROWS; ++r)
+                if (g * ESTAGE_ROWS + r < W) buf[r * EPITCH + tid] = E(it, g * ESTAGE_ROWS + r);
+            __syncthreads();                                 // (the buffer filled two stages ago has been read: its
+            if ((cw / ESTAGE_ROWS) == g && cw < W)           //  readers passed the previous barrier after reading)
+                acc = chain16_add(acc, buf + (cw % ESTAGE_ROWS) * EPITCH + cl, it * SP_THREADS, cl, L);
+            ++fill;
+        }
+    }
+    return chain16_fold(acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// rowsum16_kernel (per-layer calls: few heads in flight): grid = (bsz*n_q_heads, items), block = 1024.
+// Row maxima from the tile maxima, then the denominators above; writes rowmax[hb][w], rowsum[hb][w].
 // ---------------------------------------------------------------------------------------------
 template <int DT, int WV>
-__global__ __launch_bounds__(256) void rowsum_kernel(const ScoreArgs a) {
-    const ScoreView vw = view_of(a, blockIdx.z);
+__global__ __launch_bounds__(SP_THREADS) void rowsum16_kernel(const ScoreArgs a) {
+    const ScoreView vw = view_of(a, blockIdx.y);
     typedef typename Dt<DT>::raw raw;
-    __shared__ float m[64];
-    __shared__ float scratch[256];
-    __shared__ float wsum[4 * 64];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int chunk = blockIdx.x, hb = blockIdx.y;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const m = reinterpret_cast<float*>(smem);              // [64]
+    float* const scratch = m + 64;                                // [256]
+    float* const stage = scratch + 256;                           // [2][ESTAGE]
+    const int tid = threadIdx.x, hb = blockIdx.x;
     const int L = a.q_len, W = WV > 0 ? WV : a.window;
+    const raw* const lg = reinterpret_cast<const raw*>(vw.logits) + (int64_t)hb * L * W;
     block_row_max(vw.pmax + (int64_t)hb * a.n_tiles * W, a.n_tiles, W, m, scratch);
-    if (chunk == 0 && tid < W) vw.rowmax[(int64_t)hb * W + tid] = m[tid];
-
-    const int key = chunk * 256 + tid;
     float x[WV > 0 ? WV : 64];
-    if (key < L) load_logits<DT, WV>(reinterpret_cast<const raw*>(vw.logits) + ((int64_t)hb * L + key) * W, W, x);
-#pragma unroll
-    for (int w = 0; w < (WV > 0 ? WV : W); ++w) {
-        float e;
-        if constexpr (WV > 0) {                                    // two rows per packed-fp32 instruction
-            if ((w & 1) == 0) {
-                const f32x2 ex = exp_u20x2(f32x2{x[w], x[w + 1]} - f32x2{m[w], m[w + 1]});
-                x[w] = ex.x; x[w + 1] = ex.y;
-            }
-            e = (key < L) ? x[w] : 0.0f;
-        } else {
-            e = (key < L) ? exp_u20(x[w] - m[w]) : 0.0f;
-        }
-        e = wave_xor_sum(e);
-        if (lane == 0) wsum[wave * 64 + w] = e;
-    }
-    __syncthreads();
-    if (tid < W) {
-        const float s = ((wsum[tid] + wsum[64 + tid]) + wsum[128 + tid]) + wsum[192 + tid];
-        vw.psum[((int64_t)hb * a.n_chunks + chunk) * W + tid] = s;
+    int have = -1;                                                // iteration whose logits x[] holds
+    auto E = [&](int it, int w) -> float {
+        const int key = it * SP_THREADS + tid;
+        if (key >= L) return 0.0f;
+        if (have != it) { load_logits<DT, WV>(lg + (int64_t)key * W, W, x); have = it; }
+        return exp_u20(x[w] - m[w]);
+    };
+    const float sum = torch16_rowsums(E, L, W, stage);
+    if ((tid & 15) == 0 && (tid >> 4) < W) {
+        vw.rowmax[(int64_t)hb * W + (tid >> 4)] = m[tid >> 4];
+        vw.rowsum[(int64_t)hb * W + (tid >> 4)] = sum;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// pool_kernel: grid = (ceil(n/256), bsz*n_q_heads), block = 256.
+// pool_kernel: grid = (ceil(n/256), bsz*n_q_heads), block = 256: p = round(e * (1/sum)), window sum (cascade), round,
+// pooling — for 256 keys (+ the pooling halo) of one head, from the row maxima / sums rowsum16_kernel left.
 // ---------------------------------------------------------------------------------------------
 template <int DT, int WV>
 __global__ __launch_bounds__(256) void pool_kernel(const ScoreArgs a) {
@@ -605,25 +678,9 @@ __global__ __launch_bounds__(256) void pool_kernel(const ScoreArgs a) {
     const int L = a.q_len, W = WV > 0 ? WV : a.window, n = L - W;
     const int pad = a.pooling == KVC_POOL_NONE ? 0 : a.kernel_size / 2;
     const int j0 = blockIdx.x * 256;
-
-    // row sums: chunk partials are fetched by all threads (coalesced), then added left to right per row
-    {
-        float* stage = s_tile;                               // reuse: (256 + 64) floats per round
-        float run = 0.0f;
-        const int per_round = 320 / W;                       // chunks per round
-        for (int c0 = 0; c0 < a.n_chunks; c0 += per_round) {
-            const int cn = a.n_chunks - c0 < per_round ? a.n_chunks - c0 : per_round;
-            for (int t = tid; t < cn * W; t += 256) stage[t] = vw.psum[((int64_t)hb * a.n_chunks + c0) * W + t];
-            __syncthreads();
-            if (tid < W)
-                for (int c = 0; c < cn; ++c) { const float v = stage[c * W + tid]; run = (c0 + c) == 0 ? v : run + v; }
-            __syncthreads();
-        }
-        if (tid < W) {
-            m[tid] = vw.rowmax[(int64_t)hb * W + tid];
-            rinv[tid] = 1.0f / run;
-            if (blockIdx.x == 0) vw.rowsum[(int64_t)hb * W + tid] = run;
-        }
+    if (tid < W) {
+        m[tid] = vw.rowmax[(int64_t)hb * W + tid];
+        rinv[tid] = 1.0f / vw.rowsum[(int64_t)hb * W + tid];
     }
     __syncthreads();
 
@@ -675,63 +732,29 @@ __global__ __launch_bounds__(256) void pool_kernel(const ScoreArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// softmax_pool_kernel: rowsum_kernel + pool_kernel for one (head, item) in ONE workgroup of 1024 threads — the
-// same arithmetic in the same order (64-key butterflies, 4 per 256-key chunk left to right, chunks left to right),
-// so the bits are those of the two-kernel path.  Thread t owns keys t, t+1024, ...: a wave covers 64 consecutive
-// keys.  With KEEP > 0 the exponentials of the first pass stay in registers (KEEP iterations x WV rows) and are not
-// recomputed for the normalisation.  The per-key window sums go through a ring of four 1024-key segments in LDS so
-// that pooling reads its halo from the neighbouring segments (one barrier per iteration, nothing recomputed).
-// grid = (bsz*n_q_heads, items), block = 1024.  LDS: (iters*16 + n_chunks) * W floats + 16 KB + 1.5 KB.
+// softmax_pool_kernel: rowsum16_kernel + pool_kernel for one (head, item) in ONE workgroup of 1024 threads — the same
+// arithmetic in the same order, so the bits are those of the two-kernel path.  Thread t owns keys t, t+1024, ...  With
+// KEEP > 0 the exponentials of the first pass stay in registers (KEEP iterations x WV rows) and are not recomputed for
+// the normalisation.  The per-key window sums go through a ring of four 1024-key segments in LDS so that pooling reads
+// its halo from the neighbouring segments (one barrier per iteration, nothing recomputed); the ring shares its LDS
+// with the exponential stages of the first pass.
+// grid = (bsz*n_q_heads, items), block = 1024.  LDS: 1.5 KB + 2 stage buffers (65 KB).
 // ---------------------------------------------------------------------------------------------
-template <int WV> __device__ __forceinline__ int rs_row(int lane) {           // row a lane ends up holding
-    int row = 0, half = WV / 2;
-#pragma unroll
-    for (int s = 0; s < 6 && half >= 1; ++s, half >>= 1) row += ((lane >> s) & 1) * half;
-    return row;
-}
-// Butterfly sums over the wave for WV rows at once.  Steps with more than one row left exchange only the half of
-// the rows the partner keeps (both lanes of a pair compute the same a+b, so dropping one copy changes nothing);
-// result: the wave total of row rs_row<WV>(lane), bit-identical to wave_xor_sum() of that row.
-template <int WV, int MASK, int CNT> __device__ __forceinline__ void rs_step(float (&e)[WV], int lane) {
-    const bool bit = (lane & MASK) != 0;
-    if constexpr (CNT > 1) {
-        constexpr int H = CNT / 2;
-#pragma unroll
-        for (int r = 0; r < H; ++r) {
-            const float mine = bit ? e[r + H] : e[r], send = bit ? e[r] : e[r + H];
-            e[r] = mine + xor_lane<MASK>(send);
-        }
-    } else {
-        e[0] = e[0] + xor_lane<MASK>(e[0]);
-    }
-}
-template <int WV> __device__ __forceinline__ float wave_rows_sum(float (&e)[WV], int lane) {
-    rs_step<WV, 1, WV>(e, lane);
-    rs_step<WV, 2, (WV >= 2 ? WV / 2 : 1)>(e, lane);
-    rs_step<WV, 4, (WV >= 4 ? WV / 4 : 1)>(e, lane);
-    rs_step<WV, 8, (WV >= 8 ? WV / 8 : 1)>(e, lane);
-    rs_step<WV, 16, (WV >= 16 ? WV / 16 : 1)>(e, lane);
-    rs_step<WV, 32, (WV >= 32 ? WV / 32 : 1)>(e, lane);
-    return e[0];
-}
-
-constexpr int SP_THREADS = 1024;
 template <int DT, int WV, int KEEP>
 __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArgs a) {
     const ScoreView vw = view_of(a, blockIdx.y);
     typedef typename Dt<DT>::raw raw;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int W = WV;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x;
     const int hb = blockIdx.x;
     const int L = a.q_len, n = L - W;
     const int iters = (L + SP_THREADS - 1) / SP_THREADS;
     float* const m = reinterpret_cast<float*>(smem);              // [64]
     float* const rinv = m + 64;                                   // [64]
     float* const scratch = rinv + 64;                             // [256]
-    float* const seg = scratch + 256;                             // [4][1024]
-    float* const wsum = seg + 4 * SP_THREADS;                     // [iters*16][W]
-    float* const csum = wsum + iters * 16 * W;                    // [n_chunks][W]
+    float* const stage = scratch + 256;                           // [2][ESTAGE] (pass 1)
+    float* const seg = stage;                                     // [4][1024]   (pass 2; 4096 <= 2 * ESTAGE)
     const raw* const lg = reinterpret_cast<const raw*>(vw.logits) + (int64_t)hb * L * W;
 
     block_row_max(vw.pmax + (int64_t)hb * a.n_tiles * W, a.n_tiles, W, m, scratch);
@@ -739,9 +762,9 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
 #pragma unroll
     for (int w = 0; w < W; ++w) mr[w] = m[w];
 
-    // pass 1: exponentials and their 64-key sums
+    // pass 1: exponentials (kept in registers when they fit) and the row sums in torch's order
     float e[KEEP > 0 ? KEEP : 1][W];
-    const int my_row = rs_row<W>(lane);
+    float sum;
     if constexpr (KEEP > 0) {
         float x[KEEP][W];
 #pragma unroll
@@ -751,49 +774,70 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
         }
 #pragma unroll
         for (int it = 0; it < KEEP; ++it) {
-            if (it < iters) {
-                const int key = it * SP_THREADS + tid;
-                float t[W];
-#pragma unroll
-                for (int w = 0; w < W; w += 2) {
-                    const f32x2 ex = exp_u20x2(f32x2{x[it][w], x[it][w + 1]} - f32x2{mr[w], mr[w + 1]});
-                    e[it][w] = key < L ? ex.x : 0.0f; e[it][w + 1] = key < L ? ex.y : 0.0f;
-                    t[w] = e[it][w]; t[w + 1] = e[it][w + 1];
-                }
-                const float tot = wave_rows_sum<W>(t, lane);
-                if (lane < W) wsum[(it * 16 + wave) * W + my_row] = tot;
-            }
-        }
-    } else {
-        for (int it = 0; it < iters; ++it) {
             const int key = it * SP_THREADS + tid;
-            float x[W], t[W];
-            if (key < L) load_logits<DT, W>(lg + (int64_t)key * W, W, x);
 #pragma unroll
             for (int w = 0; w < W; w += 2) {
-                const f32x2 ex = exp_u20x2(f32x2{x[w], x[w + 1]} - f32x2{mr[w], mr[w + 1]});
-                t[w] = key < L ? ex.x : 0.0f; t[w + 1] = key < L ? ex.y : 0.0f;
+                const f32x2 ex = exp_u20x2(f32x2{x[it][w], x[it][w + 1]} - f32x2{mr[w], mr[w + 1]});
+                e[it][w] = (it < iters && key < L) ? ex.x : 0.0f; e[it][w + 1] = (it < iters && key < L) ? ex.y : 0.0f;
             }
-            const float tot = wave_rows_sum<W>(t, lane);
-            if (lane < W) wsum[(it * 16 + wave) * W + my_row] = tot;
         }
+        // (a compile-time it / w inside the staging loop: the kept values are addressed as registers)
+        const int cw = tid >> 4, cl = tid & 15;
+        constexpr int groups = (W + ESTAGE_ROWS - 1) / ESTAGE_ROWS;
+        float acc = 0.0f;
+        if (L < 16) {
+            sum = torch16_rowsums([&](int, int w) -> float { float r = 0.0f;
+#pragma unroll
+                                                             for (int ww = 0; ww < W; ++ww) r = ww == w ? e[0][ww] : r;
+                                                             return r; }, L, W, stage);
+        } else {
+            int fill = 0;
+#pragma unroll
+            for (int it = 0; it < KEEP; ++it) {
+                if (it < iters) {
+#pragma unroll
+                    for (int g = 0; g < groups; ++g) {
+                        float* buf = stage + (fill & 1) * ESTAGE;
+#pragma unroll
+                        for (int r = 0; r < ESTAGE_ROWS; ++r)
+                            if (g * ESTAGE_ROWS + r < W) buf[r * EPITCH + tid] = e[it][(g * ESTAGE_ROWS + r) < W ? (g * ESTAGE_ROWS + r) : 0];
+                        __syncthreads();
+                        if ((cw / ESTAGE_ROWS) == g && cw < W)
+                            acc = chain16_add(acc, buf + (cw % ESTAGE_ROWS) * EPITCH + cl, it * SP_THREADS, cl, L);
+                        ++fill;
+                    }
+                }
+            }
+            sum = chain16_fold(acc);
+        }
+    } else {
+        float x[W];
+        int have = -1;
+        auto E = [&](int it, int w) -> float {
+            const int key = it * SP_THREADS + tid;
+            if (key >= L) return 0.0f;
+            if (have != it) {
+                load_logits<DT, W>(lg + (int64_t)key * W, W, x);
+#pragma unroll
+                for (int ww = 0; ww < W; ww += 2) {
+                    const f32x2 ex = exp_u20x2(f32x2{x[ww], x[ww + 1]} - f32x2{mr[ww], mr[ww + 1]});
+                    x[ww] = ex.x; x[ww + 1] = ex.y;
+                }
+                have = it;
+            }
+            float r = 0.0f;
+#pragma unroll
+            for (int ww = 0; ww < W; ++ww) r = ww == w ? x[ww] : r;
+            return r;
+        };
+        sum = torch16_rowsums(E, L, W, stage);
     }
-    __syncthreads();
-    // 256-key chunk sums (4 waves left to right), then the row totals (chunks left to right)
-    for (int t = tid; t < a.n_chunks * W; t += SP_THREADS) {
-        const int c = t / W, r = t - c * W;
-        const float* g = wsum + (int64_t)(4 * c) * W + r;
-        csum[t] = ((g[0] + g[W]) + g[2 * W]) + g[3 * W];
+    if ((tid & 15) == 0 && (tid >> 4) < W) {
+        rinv[tid >> 4] = 1.0f / sum;
+        vw.rowmax[(int64_t)hb * W + (tid >> 4)] = m[tid >> 4];
+        vw.rowsum[(int64_t)hb * W + (tid >> 4)] = sum;
     }
-    __syncthreads();
-    if (tid < W) {
-        float run = csum[tid];
-        for (int c = 1; c < a.n_chunks; ++c) run = run + csum[c * W + tid];
-        rinv[tid] = 1.0f / run;
-        vw.rowmax[(int64_t)hb * W + tid] = m[tid];
-        vw.rowsum[(int64_t)hb * W + tid] = run;
-    }
-    __syncthreads();
+    __syncthreads();                                              // rinv visible; the stages are free for the ring
     float ri[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) ri[w] = rinv[w];
@@ -874,26 +918,37 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
 // batched: -25 % on the two kernels' time); the two-kernel split (many workgroups per head) otherwise — with 32 heads
 // the fused form would occupy 32 of 256 CUs.  Same bits either way; debug_stage_mask bit3 / bit4 force split / fused
 // (parity tests).
+// One workgroup per head does everything (softmax_pool_kernel) when there are enough heads x items to fill the chip (a
+// prompt's layers batched); with few heads (per-layer calls) only the serial row sums stay one workgroup per head and
+// the normalisation / pooling pass is spread over many workgroups (pool_kernel).  Same bits either way;
+// debug_stage_mask bit3 / bit4 force split / fused (parity tests).
+constexpr size_t kSoftmaxLds = (size_t)(64 + 64 + 256 + 2 * ESTAGE) * sizeof(float);
 template <int DT, int WV>
 static void launch_softmax_pool_t(const ScoreArgs& a, hipStream_t st) {
     const int m = (a.stage_mask & 7) ? (a.stage_mask & 7) : 7;
     if constexpr (WV > 0) {
         const int iters = (a.q_len + SP_THREADS - 1) / SP_THREADS;
-        const size_t lds = (size_t)(64 + 64 + 256 + 4 * SP_THREADS + (iters * 16 + a.n_chunks) * WV) * sizeof(float);
         const int heads = a.bsz * a.n_q_heads * a.n_items, ov = (a.stage_mask & 8) ? 1 : ((a.stage_mask & 16) ? 2 : 0);
-        const bool fits = lds <= 64 * 1024;
-        const bool fused = fits && ov != 1 && (ov == 2 || heads >= 128);
+        const bool fused = ov != 1 && (ov == 2 || heads >= 128);
         if (fused) {
             if (!(m & 6)) return;
             dim3 g((unsigned)(a.bsz * a.n_q_heads), (unsigned)a.n_items);
             constexpr int KEEP = 64 / WV;                     // iterations whose exponentials stay in registers
-            if (KEEP >= 2 && iters <= KEEP) hipLaunchKernelGGL((softmax_pool_kernel<DT, WV, (KEEP >= 2 ? KEEP : 0)>), g, dim3(SP_THREADS), lds, st, a);
-            else hipLaunchKernelGGL((softmax_pool_kernel<DT, WV, 0>), g, dim3(SP_THREADS), lds, st, a);
+            static LdsCache c_keep = {}, c_loop = {};
+            if (KEEP >= 2 && iters <= KEEP) {
+                (void)ensure_lds(reinterpret_cast<const void*>(&softmax_pool_kernel<DT, WV, (KEEP >= 2 ? KEEP : 0)>), kSoftmaxLds, c_keep);
+                hipLaunchKernelGGL((softmax_pool_kernel<DT, WV, (KEEP >= 2 ? KEEP : 0)>), g, dim3(SP_THREADS), kSoftmaxLds, st, a);
+            } else {
+                (void)ensure_lds(reinterpret_cast<const void*>(&softmax_pool_kernel<DT, WV, 0>), kSoftmaxLds, c_loop);
+                hipLaunchKernelGGL((softmax_pool_kernel<DT, WV, 0>), g, dim3(SP_THREADS), kSoftmaxLds, st, a);
+            }
             return;
         }
     }
-    dim3 g2((unsigned)a.n_chunks, (unsigned)(a.bsz * a.n_q_heads), (unsigned)a.n_items);
-    if (m & 2) hipLaunchKernelGGL((rowsum_kernel<DT, WV>), g2, dim3(256), 0, st, a);
+    static LdsCache c_rs = {};
+    (void)ensure_lds(reinterpret_cast<const void*>(&rowsum16_kernel<DT, WV>), kSoftmaxLds, c_rs);
+    dim3 g2((unsigned)(a.bsz * a.n_q_heads), (unsigned)a.n_items);
+    if (m & 2) hipLaunchKernelGGL((rowsum16_kernel<DT, WV>), g2, dim3(SP_THREADS), kSoftmaxLds, st, a);
     const int n = a.q_len - a.window;
     dim3 g3((unsigned)((n + 255) / 256), (unsigned)(a.bsz * a.n_q_heads), (unsigned)a.n_items);
     if (m & 4) hipLaunchKernelGGL((pool_kernel<DT, WV>), g3, dim3(256), 0, st, a);

@@ -157,6 +157,8 @@ def cases():
     for layer in (0, 15, 16, 31):
         add(f"C4_pyramidkv_8k_layer{layer}", method="pyramidkv", L=8000, cap=128, layer_idx=layer, seed=0, **big)
     add("C3_h2o_8k_2heads", method="h2o", L=8000, cap=128, Hq=2, Hkv=1, D=128, W=8, seed=0)
+    # C3 at full size (all 32 query heads over 8 KV heads; ~12 GB and ~2 min of reference time: indices + hashes only)
+    add("C3_h2o_8k", method="h2o", L=8000, cap=128, Hq=32, Hkv=8, D=128, W=8, seed=0)
     for layer in (0, 28, 31):
         add(f"C5_pyramidkv_32k_layer{layer}", method="pyramidkv", L=32000, cap=2048, layer_idx=layer, seed=0, **big)
     return cs

@@ -23,10 +23,10 @@
 //             KVCO_DOT_F64     : q·k accumulated in fp64 then rounded to fp32 (an order-free
 //                                "ideal" used to quantify 1-ulp flips vs torch's opaque GEMM).
 //   sum_mode  KVCO_SUM_TORCH16 : softmax row sum exactly as torch's AVX512 vec::reduce_all
-//                                (16 strided chains + xor butterfly 8,4,2,1).
-//             KVCO_SUM_KVC     : the GPU product's order (256-key chunks: xor butterfly
-//                                1,2,4,8,16,32 inside each 64-key group, the four groups added
-//                                left to right, chunks added left to right).
+//                                (16 strided chains + xor butterfly 8,4,2,1) — also the GPU
+//                                product's order since round 2 (round 1's own 256-key-chunk order
+//                                put 126 instead of 20 of 1 023 744 pooled scores off the reference
+//                                at L = 32000 and is gone).
 //   tie_mode  KVCO_TIES_TORCH  : libstdc++ partial_sort / nth_element+sort (== torch-CPU topk).
 //             KVCO_TIES_CANON  : value descending, index ascending.
 #include <algorithm>
@@ -46,7 +46,7 @@
 enum { KVCO_BF16 = 0, KVCO_FP16 = 1, KVCO_FP32 = 2 };
 enum { KVCO_POOL_NONE = 0, KVCO_POOL_AVG = 1, KVCO_POOL_MAX = 2 };
 enum { KVCO_DOT_CHAIN = 0, KVCO_DOT_F64 = 1 };
-enum { KVCO_SUM_TORCH16 = 0, KVCO_SUM_KVC = 1 };
+enum { KVCO_SUM_TORCH16 = 0 };
 enum { KVCO_TIES_TORCH = 0, KVCO_TIES_CANON = 1 };
 
 // ----------------------------------------------------------------------------------------
@@ -141,7 +141,7 @@ static inline float exp_u20(float x) {
 }
 
 // ----------------------------------------------------------------------------------------
-// Row sums of fp32 values in the two fixed orders.
+// Row sum of fp32 values in torch's fixed order.
 // ----------------------------------------------------------------------------------------
 static float sum_torch16(const float* x, int64_t n) {
     // vec::reduce_all<float>(+) with Vec::size()==16  (functional_base.h: reduce_all,
@@ -165,34 +165,6 @@ static float sum_torch16(const float* x, int64_t n) {
     }
     return acc[0];
 }
-static float sum_kvc(const float* x, int64_t n) {
-    // GPU order: chunks of 256 keys (one 256-thread workgroup); inside a chunk each 64-lane
-    // wave does an xor butterfly 1,2,4,8,16,32, the four wave sums are added left to right,
-    // and the chunk sums are added left to right.  Missing tail elements count as +0.0f.
-    float total = 0.0f;
-    bool first = true;
-    for (int64_t c = 0; c < n; c += 256) {
-        float wsum[4];
-        for (int w = 0; w < 4; ++w) {
-            float v[64];
-            for (int l = 0; l < 64; ++l) {
-                const int64_t i = c + w * 64 + l;
-                v[l] = i < n ? x[i] : 0.0f;
-            }
-            for (int step = 1; step < 64; step <<= 1) {
-                float nxt[64];
-                for (int l = 0; l < 64; ++l) nxt[l] = v[l] + v[l ^ step];
-                std::memcpy(v, nxt, sizeof(v));
-            }
-            wsum[w] = v[0];
-        }
-        const float cs = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
-        total = first ? cs : total + cs;
-        first = false;
-    }
-    return total;
-}
-
 // ----------------------------------------------------------------------------------------
 // torch's outer-dimension sum (SumKernel.cpp cascade "multi_row_sum"): used by
 // attn_weights[..., -W:, :-W].sum(dim=-2) (pyramidkv_utils.py:327) and by H2O's sum over all
@@ -253,7 +225,8 @@ static void softmax_row(const float* x, int64_t L, int sum_mode, float* e_tmp, f
     float m = x[0];
     for (int64_t j = 1; j < L; ++j) m = (x[j] > m) ? x[j] : m;
     for (int64_t j = 0; j < L; ++j) e_tmp[j] = exp_u20(x[j] - m);
-    const float s = (sum_mode == KVCO_SUM_TORCH16) ? sum_torch16(e_tmp, L) : sum_kvc(e_tmp, L);
+    (void)sum_mode;
+    const float s = sum_torch16(e_tmp, L);
     const float r = 1.0f / s;
     for (int64_t j = 0; j < L; ++j) p_out[j] = rnd<DT>(e_tmp[j] * r);
 }
@@ -480,7 +453,8 @@ KVCO_API int64_t kvco_pyramid_k(int64_t cap, int64_t W, int64_t q_len, int64_t l
 // Scalar probes used by tests to pin the helper arithmetic.
 KVCO_API float kvco_exp_u20(float x) { return exp_u20(x); }
 KVCO_API float kvco_sum(const float* x, int64_t n, int sum_mode) {
-    return sum_mode == KVCO_SUM_TORCH16 ? sum_torch16(x, n) : sum_kvc(x, n);
+    (void)sum_mode;
+    return sum_torch16(x, n);
 }
 KVCO_API uint16_t kvco_f32_to_f16(float f) { return f32_to_f16(f); }
 KVCO_API float kvco_f16_to_f32(uint16_t h) { return f16_to_f32(h); }

@@ -16,7 +16,7 @@ _LIB_PATH = os.path.join(_HERE, "libkvc_oracle.so")
 BF16, FP16, FP32 = 0, 1, 2
 POOL_NONE, POOL_AVG, POOL_MAX = 0, 1, 2
 DOT_CHAIN, DOT_F64 = 0, 1
-SUM_TORCH16, SUM_KVC = 0, 1
+SUM_TORCH16 = 0
 TIES_TORCH, TIES_CANON = 0, 1
 
 _DTYPE = {torch.bfloat16: BF16, torch.float16: FP16, torch.float32: FP32}
@@ -81,7 +81,7 @@ def _check_inner(t):
 
 
 def make_params(q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", full_rows=False,
-                dot_mode=DOT_CHAIN, sum_mode=SUM_KVC, tie_mode=TIES_TORCH, n_threads=0):
+                dot_mode=DOT_CHAIN, sum_mode=SUM_TORCH16, tie_mode=TIES_TORCH, n_threads=0):
     """q: [1,Hq,L,D] (any h/l strides); k,v: [1,Hq or Hkv,L,D]."""
     assert q.dim() == 4 and q.shape[0] == 1, "bsz must be 1 (reference README.md:29)"
     _check_inner(q), _check_inner(k)

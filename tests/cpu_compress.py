@@ -18,7 +18,7 @@ def oracle_compress(method, q, k, v, window, n_keep, kernel_size=5, pooling="avg
         tm = O.TIES_TORCH if tie_mode in ("torch_cpu", 0) else O.TIES_CANON
         ko, vo, idx, sc = O.compress(q, k, v, window, n_keep, kernel_size, pooling if method != _kvc.H2O else "avgpool",
                                      full_rows=method == _kvc.H2O, dot_mode=O.DOT_CHAIN,
-                                     sum_mode=O.SUM_TORCH16 if method == _kvc.H2O else O.SUM_KVC, tie_mode=tm)
+                                     sum_mode=O.SUM_TORCH16, tie_mode=tm)
     out = [ko, vo]
     if return_indices:
         out.append(idx[None])

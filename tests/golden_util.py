@@ -67,6 +67,6 @@ def pool_name(meta):
 
 
 def product_modes(oracle, meta):
-    """The oracle arithmetic that mirrors the GPU product for this method: fmaf-chain dot everywhere; softmax row sums in
-    the kvc order (256-key chunks) for the window methods and in torch's own 16-lane order for H2O (kvc_h2o.hip)."""
-    return dict(dot_mode=oracle.DOT_CHAIN, sum_mode=oracle.SUM_TORCH16 if meta["method"] == "h2o" else oracle.SUM_KVC)
+    """The oracle arithmetic that mirrors the GPU product: fmaf-chain dot products (what the gfx950 f32-input MFMA
+    computes) and softmax row sums in torch's own 16-lane order (kvc_score.hip torch16_rowsums, kvc_h2o.hip)."""
+    return dict(dot_mode=oracle.DOT_CHAIN, sum_mode=oracle.SUM_TORCH16)

@@ -31,7 +31,7 @@ def test_stages_bit_exact_vs_oracle(kvc, oracle, gpu_device, name):
     q, k, v = G.inputs(m, expanded=False)
     pool = m["pooling"]
     sc_o, lg_o, _, _ = oracle.scores(q, k, m["W"], m["kernel"], pool, want_intermediates=True,
-                                     dot_mode=oracle.DOT_CHAIN, sum_mode=oracle.SUM_KVC)
+                                     dot_mode=oracle.DOT_CHAIN, sum_mode=oracle.SUM_TORCH16)
     qd, kd, vd = _to(gpu_device, q, k, v)
     sc_g, lg_g, rmax, rsum = kvc.scores(kvc.SNAPKV, qd, kd, m["W"], m["kernel"], pool, want_intermediates=True)
     assert torch.equal(G.bits(lg_g[0].permute(0, 2, 1)), G.bits(lg_o))          # tolerance: 0 ulp
@@ -89,7 +89,7 @@ def test_config_sizes_vs_oracle_and_reference(kvc, oracle, gpu_device, name):
     ko, vo, idx, sc = kvc.compress(METHOD[m["method"]], qd, kd, vd, m["W"], m["n_keep"], m["kernel"], m["pooling"],
                                    "canonical", return_indices=True, return_scores=True)
     q, k, v = qd.cpu(), kd.cpu(), vd.cpu()
-    sc_o = oracle.scores(q, k, m["W"], m["kernel"], m["pooling"], dot_mode=oracle.DOT_CHAIN, sum_mode=oracle.SUM_KVC)
+    sc_o = oracle.scores(q, k, m["W"], m["kernel"], m["pooling"], dot_mode=oracle.DOT_CHAIN, sum_mode=oracle.SUM_TORCH16)
     assert torch.equal(G.bits(sc[0]), G.bits(sc_o))
     idx_o, _ = oracle.topk(sc_o, m["n_keep"], oracle.TIES_CANON)
     assert torch.equal(idx[0].cpu(), idx_o)
@@ -97,16 +97,12 @@ def test_config_sizes_vs_oracle_and_reference(kvc, oracle, gpu_device, name):
     assert torch.equal(G.bits(vo), G.bits(oracle.gather(v, idx_o, m["W"], m["Hq"])))
     idx_t, _ = oracle.topk(sc[0].cpu().contiguous(), m["n_keep"], oracle.TIES_TORCH)
     ref_idx = torch.from_numpy(arr["indices"])
-    heads_equal = int((idx_t == ref_idx).all(-1).sum())
-    if m["L"] >= 32000:
-        # C5 (L = 32000): measured in-container against the imported reference, 126 of 1 023 744 pooled scores differ
-        # by 1-2 bf16 ulp (torch's opaque GEMM order and its 16-lane softmax sum order vs. this build's fixed orders;
-        # even an fp64-dot + torch-sum-order restatement differs in 42).  With k up to 3978 of 31 992 such a flip can
-        # reorder one head: at least 31 of 32 heads must still be identical in set AND order.
-        assert heads_equal >= m["Hq"] - 1
-    else:
-        assert heads_equal == m["Hq"]
-        assert G.sha(oracle.gather(k, idx_t, m["W"], m["Hq"])) == m["k_out_sha256"]
+    # C5 (L = 32000) included: with the softmax row sums in torch's own 16-lane order the product's scores differ from the
+    # reference's in 20 of 1 023 744 places (torch's bf16 GEMM and exp are opaque; round 1's chunk order: 126) and none of
+    # them moves a selection — every head identical in set AND order on all three C5 fixtures.
+    assert int((idx_t == ref_idx).all(-1).sum()) == m["Hq"]
+    assert G.sha(oracle.gather(k, idx_t, m["W"], m["Hq"])) == m["k_out_sha256"]
+    assert G.sha(oracle.gather(v, idx_t, m["W"], m["Hq"])) == m["v_out_sha256"]
 
 
 @pytest.mark.parametrize("name", G.names(SCORED))
@@ -125,10 +121,10 @@ def test_exact_ties_select_vs_oracle(kvc, oracle, gpu_device, name):
     assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize("name", G.names(lambda m: SCORED(m) and m["dtype"] != "fp32" and m["L"] < 32000))
+@pytest.mark.parametrize("name", G.names(lambda m: SCORED(m) and m["dtype"] != "fp32"))
 def test_compress_exact_ties_equals_reference(kvc, gpu_device, name):
     """The headline parity gate: kvc_compress with tie_mode torch_cpu reproduces the REFERENCE's golden indices and
-    K'/V' bytes (bf16 / fp16 fixtures, small and 8k config sizes, both KV layouts)."""
+    K'/V' bytes (bf16 / fp16 fixtures: small, the 8k config sizes and the 32k -> 2048 Mistral config, both KV layouts)."""
     m, arr = G.MANIFEST[name], G.arrays(name)
     for expanded in (False, True):
         qd, kd, vd = G.inputs(m, device=gpu_device, expanded=expanded)
@@ -150,8 +146,14 @@ def test_h2o_scores_bit_exact_vs_oracle_and_reference(kvc, oracle, gpu_device, n
     q, k, v = G.inputs(m, expanded=False) if small else [t.cpu() for t in G.inputs(m, device=gpu_device, expanded=False)]
     qd, kd, vd = _to(gpu_device, q, k, v)
     sc_g = kvc.scores(kvc.H2O, qd, kd, m["W"], m["kernel"], None)
-    sc_o = oracle.scores(q, k, m["W"], m["kernel"], "avgpool", full_rows=True, **G.product_modes(oracle, m))
-    assert torch.equal(G.bits(sc_g[0]), G.bits(sc_o))                       # tolerance: 0 ulp
+    if m["Hq"] > 8:        # C3 at full size: the oracle restates one query head per KV head (0.26 Tflop on the host cores
+        g = m["Hq"] // m["Hkv"]                                             # for all 32); every head is pinned below
+        heads = [g * i + (i % g) for i in range(m["Hkv"])]                  # by the reference's golden indices and hashes
+        sc_o = oracle.scores(q[:, heads].contiguous(), k, m["W"], m["kernel"], "avgpool", full_rows=True, **G.product_modes(oracle, m))
+        assert torch.equal(G.bits(sc_g[0][heads]), G.bits(sc_o))            # tolerance: 0 ulp
+    else:
+        sc_o = oracle.scores(q, k, m["W"], m["kernel"], "avgpool", full_rows=True, **G.product_modes(oracle, m))
+        assert torch.equal(G.bits(sc_g[0]), G.bits(sc_o))                   # tolerance: 0 ulp
     ko, vo, idx = kvc.compress(kvc.H2O, qd, kd, vd, m["W"], m["n_keep"], m["kernel"], None, "torch_cpu", return_indices=True)
     ref_idx = torch.from_numpy(arr["indices"])
     if m["dtype"] == "fp32":
@@ -161,7 +163,7 @@ def test_h2o_scores_bit_exact_vs_oracle_and_reference(kvc, oracle, gpu_device, n
         assert G.sha(ko) == m["k_out_sha256"] and G.sha(vo) == m["v_out_sha256"]
     # canonical ties: same selected values, deterministic order
     idx_c = kvc.compress(kvc.H2O, qd, kd, vd, m["W"], m["n_keep"], m["kernel"], None, "canonical", return_indices=True)[2]
-    idx_oc, _ = oracle.topk(sc_o, m["n_keep"], oracle.TIES_CANON)
+    idx_oc, _ = oracle.topk(sc_g[0].cpu().contiguous(), m["n_keep"], oracle.TIES_CANON)
     assert torch.equal(idx_c[0].cpu(), idx_oc)
 
 
@@ -532,7 +534,7 @@ def test_random_shapes_end_to_end_vs_oracle(kvc, oracle, gpu_device, case):
             got = list(zip(ko, vo, bp.idx))
         for (q, k, v), (kg, vg, ig) in zip(qkv, got):
             ko_, vo_, io_, _ = oracle.compress(q.cpu(), k.cpu(), v.cpu(), W, keep, kernel, pooling, dot_mode=oracle.DOT_CHAIN,
-                                               sum_mode=oracle.SUM_KVC, tie_mode=otie)
+                                               sum_mode=oracle.SUM_TORCH16, tie_mode=otie)
             assert torch.equal(ig[0].cpu(), io_)
             assert torch.equal(G.bits(kg.cpu()), G.bits(ko_)) and torch.equal(G.bits(vg.cpu()), G.bits(vo_))
 

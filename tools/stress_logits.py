@@ -28,7 +28,7 @@ for rep in range(reps):
 try:
     from oracle import kvc_oracle as O
     q, k, v = [t.cpu() for t in qkv[0]]
-    so = O.scores(q, k, W, 7, "maxpool", dot_mode=O.DOT_CHAIN, sum_mode=O.SUM_KVC)
+    so = O.scores(q, k, W, 7, "maxpool", dot_mode=O.DOT_CHAIN, sum_mode=O.SUM_TORCH16)
     print("layer 0 vs oracle:", int((ref[0].cpu().view(torch.int16) != so.view(torch.int16)).sum()), "differing")
 except Exception as e:
     print("oracle check skipped:", e)
