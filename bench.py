@@ -2,20 +2,24 @@
 """bench.py — KV tokens compressed/sec for the post-prefill scoring+eviction hot path on MI355X.
 
 Metric (BASELINE.json): "KV tokens compressed/sec + selection-index exact-match, Llama-3-8B 8k->128".
-One "step" = the compression of ONE 8k-token prompt = 32 `update_kv` calls (one per layer of Llama-3-8B, each on
-that layer's own synthetic Q/K/V, already resident in HBM), enqueued back to back through the C-ABI
-(kvc_compress) exactly as the patched attention forward does.  tokens/step = q_len * 32 layers.
+One PROMPT = 32 `update_kv` calls (one per layer of Llama-3-8B, each on that layer's own synthetic Q/K/V, resident in
+HBM before timing), run through the C-ABI exactly as the patched attention forward does.  One STEP = `--prompts`
+consecutive prompts (default per config, chosen so that the K timed steps last about a second: the driver's
+utilisation sampler and its wall clock can see them), cycling over `--sets` distinct resident prompts so the K working
+set (0.5 GB per prompt at 8k) is never cache resident.  tokens/step = prompts * q_len * 32 layers.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2_w32|c4|c5] [--tie-mode canonical|torch_cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2_w32|c3|c4|c5] [--tie-mode torch_cpu|canonical]
+                    [--mode batch|calls] [--in-flight 1|2]
 
 N > 1 (torchrun, one rank per GPU): the path shards by independent prompts/layers with no exchange, so every rank
 runs its own replica of the workload (weak scaling); time = max over ranks, value = N * tokens / time.
-Prints ONE JSON line (rank 0).  See DESIGN.md §Measurement for the byte accounting.
+Prints ONE JSON line (rank 0).  DESIGN.md §5 has the byte accounting.
 """
 import argparse
 import ctypes
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -27,31 +31,32 @@ sys.path.insert(0, ROOT)
 from kvcache_factory_amd import _kvc, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured float4-copy rate
+MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md); the exact H2O kernel runs the f32-input MFMA (157 TF)
+HQ, HKV, D, LAYERS = 32, 8, 128, 32
 
 CONFIGS = {
-    # name: (method, q_len, cap, window, kernel, pooling, dtype, per-layer-k?)
-    "c2": dict(method="snapkv", L=8000, cap=128, W=8, kernel=7, pooling="maxpool", dtype=torch.bfloat16,
+    "c2": dict(method="snapkv", L=8000, cap=128, W=8, kernel=7, pooling="maxpool", dtype=torch.bfloat16, prompts=40,
                desc="SnapKV Llama-3-8B shapes (Hq=32,Hkv=8,D=128), seq_len=8000 -> max_capacity_prompt=128, bf16, W=8, maxpool7"),
-    "c2_w32": dict(method="snapkv", L=8000, cap=128, W=32, kernel=7, pooling="maxpool", dtype=torch.bfloat16,
+    "c2_w32": dict(method="snapkv", L=8000, cap=128, W=32, kernel=7, pooling="maxpool", dtype=torch.bfloat16, prompts=16,
                    desc="SnapKV 8k->128, W=32 (needle-runner window)"),
-    "c4": dict(method="pyramidkv", L=8000, cap=128, W=8, kernel=7, pooling="maxpool", dtype=torch.bfloat16,
+    "c4": dict(method="pyramidkv", L=8000, cap=128, W=8, kernel=7, pooling="maxpool", dtype=torch.bfloat16, prompts=32,
                desc="PyramidKV 8k, total budget 128x32 (k_l = 234..17)"),
-    "c5": dict(method="pyramidkv", L=32000, cap=2048, W=8, kernel=7, pooling="maxpool", dtype=torch.bfloat16,
+    "c5": dict(method="pyramidkv", L=32000, cap=2048, W=8, kernel=7, pooling="maxpool", dtype=torch.bfloat16, prompts=6,
                desc="PyramidKV Mistral-7B shapes, 32k -> 2048 (k_l = 3978..103)"),
+    "c3": dict(method="h2o", L=8000, cap=128, W=8, kernel=7, pooling=None, dtype=torch.bfloat16, layers=4, prompts=1,
+               desc="H2O heavy-hitter scoring, Llama-3-8B shapes, seq_len=8000 -> 128, bf16 (all 8000 query rows score; "
+                    "4 layers per prompt here)"),
 }
-CONFIGS["c3"] = dict(method="h2o", L=8000, cap=128, W=8, kernel=7, pooling=None, dtype=torch.bfloat16, layers=4,
-                     desc="H2O heavy-hitter scoring, Llama-3-8B shapes, seq_len=8000 -> 128, bf16 (all 8000 query rows score; "
-                          "4 layers per step: each layer materialises a 4.1 GB logit matrix)")
-HQ, HKV, D, LAYERS = 32, 8, 128, 32
-MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md); the H2O kernel runs the exact f32-input MFMA (157 TF peak)
 METHODS = {"snapkv": _kvc.SNAPKV, "pyramidkv": _kvc.PYRAMIDKV, "h2o": _kvc.H2O}
 
 
 def algorithmic_bytes(L, W, k, es=2):
-    """GQA-aware bytes one layer call must move (K scan once, V never scanned)."""
-    scan = HKV * L * D * es + HQ * W * D * es                       # K scan + Q window  (the K-scan kernel's share)
+    """GQA-aware bytes one layer call must move (K scan once, V never scanned).
+    Returns (K-scan kernel's share, whole path, selection stage: scores read + indices written)."""
+    scan = HKV * L * D * es + HQ * W * D * es
     compact = 2 * HQ * k * D * es + 2 * HKV * W * D * es + 2 * HQ * (k + W) * D * es + 8 * HQ * k
-    return scan, scan + compact
+    select = HQ * (L - W) * es + 8 * HQ * k
+    return scan, scan + compact, select
 
 
 def layer_budgets(cfg):
@@ -64,66 +69,55 @@ _STREAMS = {}
 
 
 def side_streams(dev, n):
-    """n HIP streams per device.  The 32 layer compressions of a prompt are independent, so the
-    drop-in calls are spread round-robin over a few streams exactly as a serving stack would overlap them."""
     key = (dev.index, n)
     if key not in _STREAMS:
         _STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
     return _STREAMS[key]
 
 
-def build_plans(cfg, dev, tie_mode, expanded, n_streams=1, seed0=0):
-    plans = []
-    ks = layer_budgets(cfg)
-    streams = side_streams(dev, n_streams)
+def make_inputs(cfg, dev, seed0, expanded=False):
+    """One resident prompt: LAYERS x (q [1,32,L,128] in [L,H,D] memory order, k, v [1,8,L,128])."""
+    out = []
     for l in range(LAYERS):
         q, k, v = synth.make_qkv(HQ, HKV, cfg["L"], D, cfg["dtype"], seed0 + l, expanded=expanded, device=dev)
         if expanded:
             k, v = k.contiguous(), v.contiguous()
-        with torch.cuda.stream(streams[l % n_streams]):          # the plan's workspace belongs to its stream
-            plan = _kvc.CompressPlan(METHODS[cfg["method"]], q, k, v, cfg["W"], ks[l], cfg["kernel"], cfg["pooling"],
-                                     tie_mode, want_indices=True)
-        plan.stream_handle = ctypes.c_void_p(streams[l % n_streams].cuda_stream)
-        plans.append(plan)
-    torch.cuda.synchronize(dev)
-    return plans, ks
+        out.append((q, k, v))
+    return out
 
 
-class BatchStep:
-    """The same 32 layer compressions through kvc_compress_batch: one library call, each kernel launched once."""
+class Prompt:
+    """One resident prompt and its compression, in one of the launch modes:
+    batch — ONE kvc_compress_batch call (every kernel launched once for the 32 layers; what the patched forward's
+            PrefillBatch does, group = all layers);  calls — 32 kvc_compress calls spread over `streams` HIP streams."""
 
-    def __init__(self, cfg, dev, tie_mode, plans, ks):
-        self.bp = _kvc.BatchPlan(METHODS[cfg["method"]], [(p.q, p.k, p.v) for p in plans], cfg["W"], ks, cfg["kernel"],
-                                 cfg["pooling"], tie_mode, want_indices=True)
-        self.stream_handle = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    def __init__(self, cfg, dev, tie_mode, mode, qkv, ks, n_streams=1, stream=None, dot_mode=None):
+        self.mode, self.dev = mode, dev
+        method = METHODS[cfg["method"]]
+        home = stream if stream is not None else torch.cuda.current_stream(dev)
+        if mode == "batch":
+            with torch.cuda.stream(home):                   # the plan's workspace belongs to the stream it runs on
+                self.bp = _kvc.BatchPlan(method, qkv, cfg["W"], ks, cfg["kernel"], cfg["pooling"], tie_mode,
+                                         want_indices=True, dot_mode=dot_mode)
+            self.handle = ctypes.c_void_p(home.cuda_stream)
+        else:
+            self.plans = []
+            streams = side_streams(dev, n_streams) if n_streams > 1 else [home]
+            for l, (q, k, v) in enumerate(qkv):
+                st = streams[l % len(streams)]
+                with torch.cuda.stream(st):
+                    p = _kvc.CompressPlan(method, q, k, v, cfg["W"], ks[l], cfg["kernel"], cfg["pooling"], tie_mode,
+                                          want_indices=True, dot_mode=dot_mode)
+                p.handle = ctypes.c_void_p(st.cuda_stream)
+                self.plans.append(p)
+            self.streams = streams
 
-    def run(self, stream=None):
-        self.bp.run(stream if stream is not None else self.stream_handle)
-
-
-def run_step(plans, stream=None):
-    for p in plans:
-        p.run(stream if stream is not None else p.stream_handle)
-
-
-def capture_step(plans, dev):
-    """One step (32 layer calls over their streams) as a HIP graph: fork from the capture stream, run, join.
-    Replaying it costs one host call per step instead of ~130 kernel launches."""
-    handles = {p.stream_handle.value for p in plans}
-    tstreams = [s for sl in _STREAMS.values() for s in sl if s.cuda_stream in handles and s.device == dev]
-    g = torch.cuda.CUDAGraph()
-    cap = torch.cuda.Stream(device=dev)
-    with torch.cuda.graph(g, stream=cap):
-        fork = torch.cuda.Event()
-        fork.record(cap)
-        for s in tstreams:
-            s.wait_event(fork)
-        run_step(plans)
-        for s in tstreams:
-            e = torch.cuda.Event()
-            e.record(s)
-            cap.wait_event(e)
-    return g
+    def run(self):
+        if self.mode == "batch":
+            self.bp.run(self.handle)
+        else:
+            for p in self.plans:
+                p.run(p.handle)
 
 
 def reduce_max_time(dt, dist, device):
@@ -146,147 +140,184 @@ def rank_seed(rank):
     return 1000 * rank
 
 
-def time_steps(plans, steps, warmup, dev, dist, graph=None):
-    if graph is not None:
-        for _ in range(warmup):
-            graph.replay()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            graph.replay()
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-        return reduce_max_time(time.perf_counter() - t0, dist, dev)
+def time_steps(prompts, per_step, steps, warmup, dev, dist, streams=None):
+    """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize on both sides.  A step runs `per_step`
+    prompts, cycling over the resident ones (each on the stream(s) it was built for; `streams` lists every side stream in
+    use so that a step's end mark waits for all of them).  Returns (wall seconds of the K steps, per-step HIP-event ms)."""
+    def step(i0):
+        for j in range(per_step):
+            prompts[(i0 + j) % len(prompts)].run()
+    cur = torch.cuda.current_stream(dev)
+
+    def mark():
+        e = torch.cuda.Event(enable_timing=True)
+        for s in streams or ():                             # a step ends when every stream is done with it
+            cur.wait_stream(s)
+        e.record(cur)
+        for s in streams or ():
+            s.wait_stream(cur)
+        return e
+    i = 0
     for _ in range(warmup):
-        run_step(plans)
+        step(i)
+        i += per_step
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
+    marks = [mark()]
     t0 = time.perf_counter()
     for _ in range(steps):
-        run_step(plans)
+        step(i)
+        i += per_step
+        marks.append(mark())
     torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-    return reduce_max_time(time.perf_counter() - t0, dist, dev)
+    per = [marks[j].elapsed_time(marks[j + 1]) for j in range(steps)]
+    return reduce_max_time(dt, dist, dev), per
 
 
-def time_scan_kernel(plans, dev, reps=20):
-    """Average duration of ONE launch of the dominant kernel (the K-scan / window-logits kernel), measured live with
-    HIP events on the launch stream: kvc_scores with debug_stage_mask=1 enqueues only that kernel."""
-    lib = _kvc.lib()
-    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    calls = []
-    for p in plans:
-        pp = _kvc.Params.from_buffer_copy(p.p)
-        pp.debug_stage_mask = 1
-        sc = torch.empty(1, HQ, p.k.shape[2] - p.p.window, dtype=p.k.dtype, device=dev)
-        calls.append((pp, p, sc))
+def kernel_breakdown(prompt, dev, tie_mode, reps=10):
+    """Live HIP-event time of each kernel of ONE batched launch (32 layers), by running the same kvc_compress_batch with
+    debug_stage_mask subsets on the launch stream: bit0 K scan, bits1-2 softmax+pool, bit5 selection (+ gather), bit6
+    gather alone."""
+    bp = prompt.bp
+    stream = prompt.handle
 
-    def sweep():
-        for pp, p, sc in calls:
-            rc = lib.kvc_scores(ctypes.byref(pp), _kvc._ptr(p.q), _kvc._ptr(p.k), _kvc._ptr(sc), _kvc._ptr(p.ws), p.nbytes, stream)
-            assert rc == 0, lib.kvc_last_error()
-    sweep()
-    torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        sweep()
-    e1.record()
-    torch.cuda.synchronize(dev)
-    return e0.elapsed_time(e1) * 1e-3 / (reps * len(calls))
+    def timed(mask):
+        pp = _kvc.Params.from_buffer_copy(bp.p)
+        pp.debug_stage_mask = mask
+        assert bp.call(params=pp, stream=stream) == 0, _kvc.lib().kvc_last_error()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            bp.call(params=pp, stream=stream)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) * 1e-3 / reps
+    bp.run(stream)
+    out = {"logits_kernel": timed(1), "softmax_pool_kernel": timed(6)}
+    if tie_mode == "torch_cpu":
+        g = timed(64)
+        out["select_exact_kernel"] = max(timed(32) - g, 0.0)
+        out["gather_kernel"] = g
+    else:
+        out["select_kernel (selection + fused gather)"] = timed(32)
+    return out
 
 
-def time_scan_kernel_batch(bstep, dev, reps=10):
-    """Same for the batched call: ONE logits_kernel launch covers all 32 layers (debug_stage_mask=1 on kvc_compress_batch)."""
-    lib, bp = _kvc.lib(), bstep.bp
-    pp = _kvc.Params.from_buffer_copy(bp.p)
-    pp.debug_stage_mask = 1
-    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+def pmc_traffic(kernel_prefix, tag="r02"):
+    """HBM bytes per launch of one kernel from the committed PMC passes (profiles/<tag>_pmc_batch_*.csv; separate
+    rocprofv3 --pmc runs of tools/prof_driver.py; FETCH_SIZE doubled per the gfx950 correction).  None if absent."""
+    import csv
 
-    def launch():
-        rc = lib.kvc_compress_batch(ctypes.byref(pp), bp.n, bp._keep, bp._q, bp._k, bp._v, bp._ko, bp._vo, bp._ix, None,
-                                    _kvc._ptr(bp.ws), bp.nbytes, stream)
-        assert rc == 0, lib.kvc_last_error()
-    launch()
-    torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        launch()
-    e1.record()
-    torch.cuda.synchronize(dev)
-    return e0.elapsed_time(e1) * 1e-3 / reps
+    def one(name):
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_batch_{name}.csv")
+        with open(path) as fh:
+            return [float(r["mean_per_dispatch"]) for r in csv.DictReader(fh)
+                    if r["kernel"].startswith(kernel_prefix) and r["counter"] == name][0]
+    try:
+        return (2.0 * one("FETCH_SIZE") + one("WRITE_SIZE")) * 1024.0
+    except Exception:
+        return None
 
 
 def cpu_baseline(cfg, budget_s=12.0, dev=None):
-    """The CPU oracle (a port of the reference's algorithm, oracle/kvc_oracle.cpp) timed on this host's cores on a
-    bounded sample of the same workload: whole layer calls of the bench config, repeated for ~budget_s seconds."""
+    """The reference's CPU path on this host's cores, on a bounded sample of the same workload: the stock torch-CPU op
+    sequence of pyramidkv_utils.py:317-346 (what the reference executes; `value`) and the oracle port
+    (oracle/kvc_oracle.cpp, OpenMP over heads) as a side figure; parity counters of the HIP path vs the oracle on the same
+    layer (H2O: one query head per KV head on the oracle side)."""
     from oracle import kvc_oracle as O      # cpu_baseline leg only (the checker, timed as the baseline)
+    import math
+    import torch.nn.functional as F
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:  # pragma: no cover
         avail = os.cpu_count() or 1
     threads = max(1, min(avail, 16))          # the GPU box gives one GPU's share of the host: 16 cores
-    L = cfg["L"]
+    L, W = cfg["L"], cfg["W"]
+    h2o = cfg["method"] == "h2o"
     q, k, v = synth.make_qkv(HQ, HKV, L, D, cfg["dtype"], 0)
     n_keep = layer_budgets(cfg)[0]
-    O.compress(q, k, v, cfg["W"], n_keep, cfg["kernel"], cfg["pooling"], n_threads=threads)     # warm-up
-    t0, n = time.perf_counter(), 0
-    while time.perf_counter() - t0 < budget_s:
-        O.compress(q, k, v, cfg["W"], n_keep, cfg["kernel"], cfg["pooling"], n_threads=threads)
-        n += 1
-    dt = time.perf_counter() - t0
-    out = {"value": n * L / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
-           "sample": f"{n} layer calls of the bench config (L={L}, k={n_keep}, all {HQ} heads), oracle/kvc_oracle.cpp, OpenMP over heads"}
-    # the stock torch-CPU op sequence the reference executes (pyramidkv_utils.py:317-346), same inputs, same host
-    try:
-        import math
-        import torch.nn.functional as F
-        torch.set_num_threads(threads)
+    out = {"unit": "tokens/s", "cores": threads, "kind": "port"}
+    torch.set_num_threads(threads)
+
+    def mask_block(aw):
+        mask = torch.full((W, W), torch.finfo(aw.dtype).min)
+        mc = torch.arange(W)
+        mask.masked_fill_(mc < (mc + 1).view(W, 1), 0)
+        aw[:, :, -W:, -W:] += mask[None, None]
+    if not h2o:
         kx, vx = k.repeat_interleave(HQ // HKV, 1), v.repeat_interleave(HQ // HKV, 1)
-        W = cfg["W"]
 
         def ref_ops():
             aw = torch.matmul(q[..., -W:, :], kx.transpose(2, 3)) / math.sqrt(D)
-            mask = torch.full((W, W), torch.finfo(aw.dtype).min)
-            mc = torch.arange(W)
-            mask.masked_fill_(mc < (mc + 1).view(W, 1), 0)
-            aw[:, :, -W:, -W:] += mask[None, None]
+            mask_block(aw)
             aw = F.softmax(aw, dim=-1, dtype=torch.float32).to(q.dtype)
             s = aw[:, :, -W:, :-W].sum(dim=-2)
             c = (F.max_pool1d if cfg["pooling"] == "maxpool" else F.avg_pool1d)(s, kernel_size=cfg["kernel"], padding=cfg["kernel"] // 2, stride=1)
             idx = c.topk(n_keep, dim=-1).indices.unsqueeze(-1).expand(-1, -1, -1, D)
             return (torch.cat([kx[:, :, :-W].gather(2, idx), kx[:, :, -W:]], 2), torch.cat([vx[:, :, :-W].gather(2, idx), vx[:, :, -W:]], 2))
-        for _ in range(3):
+        for _ in range(10):
             ref_ops()
+        ts = []
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < budget_s or len(ts) < 5:
+            t1 = time.perf_counter()
+            ref_ops()
+            ts.append(time.perf_counter() - t1)
+        out["value"] = L / statistics.median(ts)
+        out["sample"] = (f"{len(ts)} layer calls of the bench config (L={L}, k={n_keep}, all {HQ} heads, K/V repeat_kv-expanded as the "
+                         f"reference passes them), stock torch-CPU op sequence of pyramidkv_utils.py:317-346, torch.set_num_threads({threads}), "
+                         f"10 warm-ups, median")
+        O.compress(q, k, v, W, n_keep, cfg["kernel"], cfg["pooling"], n_threads=threads)     # warm-up
         t0, n = time.perf_counter(), 0
-        while time.perf_counter() - t0 < min(budget_s, 6.0):
-            ref_ops()
+        while time.perf_counter() - t0 < 4.0:
+            O.compress(q, k, v, W, n_keep, cfg["kernel"], cfg["pooling"], n_threads=threads)
             n += 1
-        out["torch_cpu_ops_tokens_per_s"] = n * L / (time.perf_counter() - t0)
-        out["torch_cpu_ops_threads"] = threads
-    except Exception as e:  # pragma: no cover
-        out["torch_cpu_ops_error"] = repr(e)
-    # parity counters on the same layer (SURVEY 8d): the HIP path against the oracle's product arithmetic, both tie modes
+        out["oracle_port_tokens_per_s"] = n * L / (time.perf_counter() - t0)
+    else:
+        # H2O: the reference's op sequence needs ~12 GB and ~70 s per layer for 32 heads; sample = 2 query heads of one KV head
+        qs, ks_ = q[:, :2], k[:, :1].repeat_interleave(2, 1)
+        t0 = time.perf_counter()
+        aw = torch.matmul(qs, ks_.transpose(2, 3)) / math.sqrt(D)
+        mask_block(aw)
+        aw = F.softmax(aw, dim=-1, dtype=torch.float32).to(q.dtype)
+        s = aw[:, :, :, :-W].sum(dim=-2)
+        s.topk(n_keep, dim=-1)
+        dt = time.perf_counter() - t0
+        out["value"] = L / (dt * HQ / 2)
+        out["sample"] = (f"2 of {HQ} query heads of one layer call (L={L}), stock torch-CPU op sequence of pyramidkv_utils.py:544-561, "
+                         f"{threads} threads, scaled to {HQ} heads")
     try:
-        if dev is not None and cfg["method"] != "h2o":
+        if dev is not None:
             qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
             par = {}
+            pool = cfg["pooling"] if not h2o else None
+            if h2o:
+                g = HQ // HKV
+                heads = [g * i + (i % g) for i in range(HKV)]
+                qo = q[:, heads].contiguous()
             for tie, otie in (("canonical", O.TIES_CANON), ("torch_cpu", O.TIES_TORCH)):
-                ko, vo, idx, sc = O.compress(q, k, v, cfg["W"], n_keep, cfg["kernel"], cfg["pooling"], dot_mode=O.DOT_CHAIN,
-                                             sum_mode=O.SUM_TORCH16, tie_mode=otie, n_threads=threads)
-                g = _kvc.compress(METHODS[cfg["method"]], qd, kd, vd, cfg["W"], n_keep, cfg["kernel"], cfg["pooling"], tie,
-                                  return_indices=True, return_scores=True)
-                gi, gs = g[2][0].cpu(), g[3][0].cpu()
+                got = _kvc.compress(METHODS[cfg["method"]], qd, kd, vd, W, n_keep, cfg["kernel"], pool, tie,
+                                    return_indices=True, return_scores=True)
+                gi, gs = got[2][0].cpu(), got[3][0].cpu()
+                if h2o:
+                    sc = O.scores(qo, k, W, cfg["kernel"], "avgpool", full_rows=True, dot_mode=O.DOT_CHAIN, sum_mode=O.SUM_TORCH16, n_threads=threads)
+                    idx, _ = O.topk(sc, n_keep, otie, n_threads=threads)
+                    ko = O.gather(k, idx, W, HKV)
+                    gi, gs, gk = gi[heads], gs[heads], got[0][:, heads].cpu()
+                    kv_equal = bool(torch.equal(gk, ko))
+                else:
+                    ko, vo, idx, sc = O.compress(q, k, v, W, n_keep, cfg["kernel"], cfg["pooling"], dot_mode=O.DOT_CHAIN,
+                                                 sum_mode=O.SUM_TORCH16, tie_mode=otie, n_threads=threads)
+                    kv_equal = bool(torch.equal(got[0].cpu(), ko) and torch.equal(got[1].cpu(), vo))
                 par[tie] = {"score_bits_differing": int((gs.view(torch.int16) != sc.view(torch.int16)).sum()),
                             "scores_compared": int(sc.numel()),
                             "heads_with_identical_indices": int((gi == idx).all(dim=1).sum()), "heads": int(idx.shape[0]),
-                            "k_out_v_out_bytes_equal": bool(torch.equal(g[0].cpu(), ko) and torch.equal(g[1].cpu(), vo))}
+                            "k_out_v_out_bytes_equal": kv_equal}
             out["parity_vs_oracle_same_layer"] = par
     except Exception as e:  # pragma: no cover
         out["parity_error"] = repr(e)
@@ -296,21 +327,25 @@ def cpu_baseline(cfg, budget_s=12.0, dev=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--tie-mode", default="torch_cpu", choices=["canonical", "torch_cpu"],
                     help="torch_cpu (default, the clusters' default): indices bit-identical to the reference's CPU run, "
                          "ties included; canonical: value desc / index asc, faster, differs only inside tie groups")
     ap.add_argument("--mode", default="batch", choices=["batch", "calls"],
-                    help="batch: one kvc_compress_batch call per step (all 32 layers per kernel launch); "
-                         "calls: 32 kvc_compress calls per step spread over --streams streams")
-    ap.add_argument("--streams", type=int, default=16, help="HIP streams the 32 independent layer calls are spread over")
-    ap.add_argument("--no-graph", action="store_true", help="enqueue every kvc_compress call from the host instead of replaying a HIP graph of the step")
+                    help="batch: one kvc_compress_batch call per prompt (all 32 layers per kernel launch); "
+                         "calls: 32 kvc_compress calls per prompt spread over --streams streams")
+    ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
+                    help="prompts in flight: 2 alternates consecutive prompts between two HIP streams (a serving stack's overlap: "
+                         "the latency-bound exact top-k of one prompt runs beside the K scan of the next)")
+    ap.add_argument("--prompts", type=int, default=0, help="prompts per step (0: the config's default, sized for ~20 ms steps)")
+    ap.add_argument("--sets", type=int, default=2, help="distinct resident prompts the step cycles over")
+    ap.add_argument("--streams", type=int, default=16, help="calls mode: HIP streams the 32 independent layer calls are spread over")
     ap.add_argument("--dot-mode", default="exact", choices=["exact", "mfma16"],
                     help="exact: f32-MFMA fmaf chain (bit-identical to the oracle); mfma16: packed bf16 MFMA scan (tolerance mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (expanded K/V, exact ties)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -325,149 +360,168 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     cfg = CONFIGS[a.config]
-    _kvc.DOT_MODE = a.dot_mode                 # default dot_mode of every plan built below
+    _kvc.DOT_MODE = a.dot_mode
     global LAYERS
     LAYERS = cfg.get("layers", LAYERS)
-    if cfg["method"] == "h2o":
-        a.mode, a.no_extras = "calls", True            # one 4.1 GB logit matrix at a time: sequential calls, one stream
-        a.streams = 1
-
-    plans, ks = build_plans(cfg, dev, a.tie_mode, expanded=False, n_streams=a.streams, seed0=rank_seed(rank))
-    run_step(plans)                      # first call outside any capture (one-time LDS attribute setup)
+    h2o = cfg["method"] == "h2o"
+    if h2o:
+        a.mode, a.in_flight, a.streams = "calls", 1, 1       # compute-bound single calls
+    per_step = a.prompts or cfg["prompts"]
+    ks = layer_budgets(cfg)
+    n_sets = max(a.sets, a.in_flight)
+    inputs = [make_inputs(cfg, dev, rank_seed(rank) + 100 * s) for s in range(n_sets)]
+    fl = side_streams(dev, 2) if a.in_flight == 2 else None
+    prompts = [Prompt(cfg, dev, a.tie_mode, a.mode, inputs[s], ks, a.streams if a.mode == "calls" else 1,
+                      stream=fl[s % 2] if fl else None) for s in range(n_sets)]
+    used = list(fl or ()) + (prompts[0].streams if a.mode == "calls" and a.streams > 1 else [])
+    for p in prompts:
+        p.run()                                            # first call outside the timed region (one-time attribute setup)
     torch.cuda.synchronize(dev)
-    graph, launch_mode = None, "host-enqueued kvc_compress calls"
-    call_plans = plans
-    if a.mode == "batch":
-        plans = [BatchStep(cfg, dev, a.tie_mode, call_plans, ks)]
-        run_step(plans)
-        torch.cuda.synchronize(dev)
-        launch_mode = "one kvc_compress_batch call per step: every kernel launched once for the 32 layers"
-    elif not a.no_graph:
-        try:
-            graph = capture_step(plans, dev)
-            launch_mode = "HIP graph of the step (32 kvc_compress calls captured once, replayed per step)"
-        except Exception as e:  # pragma: no cover
-            launch_mode = f"host-enqueued (graph capture failed: {e})"
-            graph = None
-    dt = time_steps(plans, a.steps, a.warmup, dev, dist, graph)
-    tokens_per_step = cfg["L"] * LAYERS
+
+    dt, per = time_steps(prompts, per_step, a.steps, a.warmup, dev, dist, used)
+    tokens_per_step = per_step * cfg["L"] * LAYERS
     value = job_value(world, a.steps, tokens_per_step, dt)
+    med_ms = statistics.median(per)
+    t_layer = dt / a.steps / per_step / LAYERS
 
     out = {
         "metric": "KV tokens compressed/sec", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": cfg["desc"], "name": a.config, "layers_per_step": LAYERS, "q_len": cfg["L"], "budget": cfg["cap"],
+        "config": {"workload": cfg["desc"], "name": a.config, "layers_per_prompt": LAYERS, "prompts_per_step": per_step,
+                   "resident_prompt_sets": n_sets, "q_len": cfg["L"], "budget": cfg["cap"],
                    "kv_layout": "gqa_native [1,8,L,128] as the patched attention forward hands K/V over",
-                   "tie_mode": a.tie_mode, "dot_mode": a.dot_mode, "mode": a.mode, "streams": a.streams if a.mode == "calls" else 1, "launch": launch_mode, "per_layer_us": dt / a.steps / LAYERS * 1e6,
+                   "tie_mode": a.tie_mode, "dot_mode": a.dot_mode, "mode": a.mode, "prompts_in_flight": a.in_flight,
+                   "streams": a.streams if a.mode == "calls" else a.in_flight,
+                   "launch": ("one kvc_compress_batch call per prompt: every kernel launched once for the 32 layers" if a.mode == "batch"
+                              else "32 host-enqueued kvc_compress calls per prompt"),
                    "multi_gpu": "replicas, no collective"},
+        "median_ms_per_step": med_ms, "value_from_median_step": world * tokens_per_step / (med_ms * 1e-3),
+        "per_layer_us": t_layer * 1e6, "us_per_prompt": dt / a.steps / per_step * 1e6,
     }
     if rank == 0:
-        # ---- roofline of the dominant kernel (K scan), live HIP-event timing ----
-        es = 2
-        scan_b, path_b = algorithmic_bytes(cfg["L"], cfg["W"], sum(ks) / len(ks), es)
-        if cfg["method"] == "h2o":
-            t_scan = None
-        elif a.mode == "batch":
-            t_scan = time_scan_kernel_batch(plans[0], dev)        # one launch = 32 layers
-            scan_b *= LAYERS
-        else:
-            t_scan = time_scan_kernel(call_plans, dev)
-        if cfg["method"] == "h2o":
-            # F = 2*Hq*L*L*D flop per layer (one QK^T); achieved over the whole per-layer time
-            flops = 2.0 * HQ * cfg["L"] * cfg["L"] * D
-            t_layer = dt / a.steps / LAYERS
-            out["roofline"] = {"bound": "mfma", "kernel": "h2o_logits_kernel (+ row/column softmax sums)", "achieved": flops / t_layer / 1e12,
-                               "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / t_layer / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
+        kmean = sum(ks) / len(ks)
+        scan_b, path_b, sel_b = algorithmic_bytes(cfg["L"], cfg["W"], kmean)
+        out["path_algorithmic_bytes_per_layer"] = path_b
+        out["path_achieved_GBs"] = path_b / t_layer / 1e9
+        out["path_frac"] = path_b / t_layer / 1e9 / HBM_PEAK_GBS
+        if h2o:
+            flops = 2.0 * HQ * cfg["L"] * cfg["L"] * D       # one QK^T per layer
+            out["roofline"] = {"bound": "mfma", "kernel": "h2o scoring kernels (logits + row / column softmax sums)",
+                               "achieved": flops / t_layer / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": flops / t_layer / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
                                "launch_us": t_layer * 1e6, "algorithmic_flops_per_layer": flops,
-                               "note": "exact-arithmetic version: f32-input MFMA (157 TF peak), logits materialised once"}
-            t_scan = 1.0
-        out.setdefault("roofline", {"bound": "hbm", "kernel": "logits_kernel (K scan + window QK^T)", "achieved": scan_b / t_scan / 1e9,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": scan_b / t_scan / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                           "launch_us": t_scan * 1e6, "algorithmic_bytes_per_launch": scan_b,
-                           "units_per_launch": f"{cfg['L'] * (LAYERS if a.mode == 'batch' else 1)} tokens x 2056 B/token",
-                           "path_achieved_GBs": path_b / (dt / a.steps / LAYERS) / 1e9,
-                           "path_frac": path_b / (dt / a.steps / LAYERS) / 1e9 / HBM_PEAK_GBS,
-                           "path_algorithmic_bytes_per_layer": path_b})
-        try:      # HBM bytes of the K-scan kernel from the committed PMC pass (profiles/, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE;
-            #   gfx950 correction: FETCH_SIZE counts half of a wide coalesced read).  KB per dispatch -> bytes per launch.
-            import csv
-            def _pmc(name):
-                with open(os.path.join(ROOT, "profiles", f"r01_pmc_{'batch_' if a.mode == 'batch' else ''}{name}.csv")) as fh:
-                    return [float(r["mean_per_dispatch"]) for r in csv.DictReader(fh)
-                            if r["kernel"].startswith("kvc::logits_kernel") and r["counter"] == name][0]
-            if a.config == "c2":
-                out["roofline"]["traffic"] = (2.0 * _pmc("FETCH_SIZE") + _pmc("WRITE_SIZE")) * 1024.0
-                out["roofline"]["traffic_source"] = ("profiles/r01_pmc_[batch_]{FETCH,WRITE}_SIZE.csv: separate rocprofv3 --pmc passes of the same "
-                                                     "launch; FETCH_SIZE doubled per the gfx950 correction; includes the logits the kernel writes")
-        except Exception:
-            pass
-        if not a.no_extras and world == 1:
+                               "note": "exact arithmetic: f32-input MFMA (157 TF peak), scored against the bf16 MFMA peak"}
+        elif a.mode == "batch":
+            kt = kernel_breakdown(prompts[0], dev, a.tie_mode)
+            tot = sum(kt.values())
+            out["kernels_us_per_32_layer_launch"] = {k_: round(v_ * 1e6, 1) for k_, v_ in kt.items()}
+            out["kernel_time_share"] = {k_: round(v_ / tot, 3) for k_, v_ in kt.items()}
+            dom = max(kt, key=kt.get)
+            t_scan = kt["logits_kernel"]
+            kscan = {"kscan_kernel": "logits_kernel (K scan + window QK^T)", "kscan_launch_us": t_scan * 1e6,
+                     "kscan_algorithmic_bytes_per_launch": scan_b * LAYERS, "kscan_achieved_GBs": scan_b * LAYERS / t_scan / 1e9,
+                     "kscan_frac": scan_b * LAYERS / t_scan / 1e9 / HBM_PEAK_GBS,
+                     "kscan_traffic": pmc_traffic("kvc::logits_kernel"),
+                     "kscan_traffic_source": "profiles/r02_pmc_batch_{FETCH,WRITE}_SIZE.csv (separate rocprofv3 --pmc passes of "
+                                             "tools/prof_driver.py; FETCH_SIZE x2 gfx950 correction; includes the logits it writes)"}
+            if dom == "logits_kernel":
+                out["roofline"] = {"bound": "hbm", "kernel": kscan["kscan_kernel"], "achieved": kscan["kscan_achieved_GBs"],
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kscan["kscan_frac"], "traffic": kscan["kscan_traffic"],
+                                   "launch_us": t_scan * 1e6, "algorithmic_bytes_per_launch": scan_b * LAYERS,
+                                   "units_per_launch": f"{cfg['L'] * LAYERS} tokens x {scan_b / cfg['L']:.0f} B/token",
+                                   "time_share": kt[dom] / tot}
+            else:
+                t_dom = kt[dom]
+                out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": sel_b * LAYERS / t_dom / 1e9, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": sel_b * LAYERS / t_dom / 1e9 / HBM_PEAK_GBS,
+                                   "traffic": pmc_traffic("kvc::select"), "launch_us": t_dom * 1e6,
+                                   "algorithmic_bytes_per_launch": sel_b * LAYERS, "time_share": t_dom / tot,
+                                   "note": "latency-bound: one wave per head walks libstdc++'s heap / partition moves (a single dependent "
+                                           "chain per head, DESIGN.md §3); its bytes are the pooled scores it reads and the indices it writes"}
+            out["roofline"].update(kscan)
+        else:
+            out["roofline"] = {"bound": "hbm", "kernel": "whole per-call path (latency-bound launches)", "achieved": path_b / t_layer / 1e9,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": path_b / t_layer / 1e9 / HBM_PEAK_GBS, "traffic": None}
+        if not a.no_extras and world == 1 and not h2o:
             extra = {}
+            half = max(5, a.steps // 5)
+
+            def quick(ps, streams=None, per=max(1, per_step // 4)):
+                d, _ = time_steps(ps, per, half, 2, dev, None, streams)
+                return half * per * cfg["L"] * LAYERS / d
             other = "torch_cpu" if a.tie_mode == "canonical" else "canonical"
-            half = max(2, a.steps // 2)
             try:
-                if a.mode == "batch":
-                    p2 = [BatchStep(cfg, dev, other, call_plans, ks)]
-                else:
-                    p2, _ = build_plans(cfg, dev, other, expanded=False, n_streams=a.streams)
-                d2 = time_steps(p2, half, 1, dev, None)
-                extra[f"tokens_per_s_tie_mode_{other}"] = half * tokens_per_step / d2
-                del p2
+                extra[f"tokens_per_s_tie_mode_{other}"] = quick([Prompt(cfg, dev, other, "batch", inputs[s], ks) for s in range(n_sets)])
             except Exception as e:
                 extra[f"tie_mode_{other}_error"] = str(e)
-            if a.mode == "batch":
-                # two prompts in flight: consecutive steps alternate between two HIP streams (own outputs and workspace
-                # each), so the latency-bound select of one prompt overlaps the K scan / softmax of the next
-                try:
-                    s2 = torch.cuda.Stream(device=dev)
-                    with torch.cuda.stream(s2):
-                        alt = BatchStep(cfg, dev, a.tie_mode, call_plans, ks)
+            if a.in_flight == 1 and a.mode == "batch":
+                try:        # two prompts in flight: own stream, outputs and workspace each; with parity counters of its own
+                    s2 = side_streams(dev, 2)
+                    pf = [Prompt(cfg, dev, a.tie_mode, "batch", inputs[s], ks, stream=s2[s % 2]) for s in range(n_sets)]
+                    extra["tokens_per_s_two_prompts_in_flight"] = quick(pf, s2)
                     torch.cuda.synchronize(dev)
-                    pair = [plans[0], alt]
-                    for i in range(2):
-                        pair[i % 2].run()
-                    torch.cuda.synchronize(dev)
-                    n2 = 2 * half
-                    t0 = time.perf_counter()
-                    for i in range(n2):
-                        pair[i % 2].run()
-                    torch.cuda.synchronize(dev)
-                    extra["tokens_per_s_two_prompts_in_flight_2_streams"] = n2 * tokens_per_step / (time.perf_counter() - t0)
-                    del alt, pair
-                except Exception as e:
-                    extra["two_streams_error"] = str(e)
-            if a.mode == "batch" and a.dot_mode == "exact":
-                try:
-                    _kvc.DOT_MODE = "mfma16"
-                    pf = [BatchStep(cfg, dev, a.tie_mode, call_plans, ks)]
-                    df = time_steps(pf, half, 1, dev, None)
-                    extra["tokens_per_s_dot_mode_mfma16_tolerance_mode"] = half * tokens_per_step / df
+                    same = all(torch.equal(x, y) for pa, pb in zip(pf, prompts) for x, y in
+                               zip(pa.bp.k_out + pa.bp.v_out + pa.bp.idx, pb.bp.k_out + pb.bp.v_out + pb.bp.idx))
+                    extra["two_prompts_in_flight_outputs_identical_to_single_stream"] = bool(same)
                     del pf
                 except Exception as e:
+                    extra["two_in_flight_error"] = str(e)
+            if a.mode == "batch" and a.dot_mode == "exact":
+                try:
+                    extra["tokens_per_s_dot_mode_mfma16_tolerance_mode"] = quick(
+                        [Prompt(cfg, dev, a.tie_mode, "batch", inputs[s], ks, dot_mode="mfma16") for s in range(n_sets)])
+                except Exception as e:
                     extra["dot_mode_mfma16_error"] = str(e)
-                finally:
-                    _kvc.DOT_MODE = a.dot_mode
             try:
-                d0 = time_steps(call_plans, half, 1, dev, None)
-                extra[f"tokens_per_s_32_kvc_compress_calls_{a.streams}_streams_host_enqueued"] = half * tokens_per_step / d0
+                pc = [Prompt(cfg, dev, a.tie_mode, "calls", inputs[0], ks, a.streams)]
+                extra[f"tokens_per_s_32_kvc_compress_calls_{a.streams}_streams"] = quick(pc, pc[0].streams, per=2)
+                pc1 = [Prompt(cfg, dev, a.tie_mode, "calls", inputs[0], ks, 1)]
+                extra["tokens_per_s_32_kvc_compress_calls_single_stream"] = quick(pc1, per=1)
+                del pc, pc1
             except Exception as e:
                 extra["calls_error"] = str(e)
-            try:
-                p1, _ = build_plans(cfg, dev, a.tie_mode, expanded=False, n_streams=1)
-                d1 = time_steps(p1, max(2, a.steps // 2), 1, dev, None)
-                extra["tokens_per_s_single_stream_host_enqueued"] = max(2, a.steps // 2) * tokens_per_step / d1
-
-                del p1
-            except Exception as e:
-                extra["single_stream_error"] = str(e)
-            try:
-                p3, _ = build_plans(cfg, dev, a.tie_mode, expanded=True, n_streams=a.streams)
-                d3 = time_steps(p3, max(2, a.steps // 2), 1, dev, None)
-                extra["tokens_per_s_expanded_kv_as_reference_passes"] = max(2, a.steps // 2) * tokens_per_step / d3
-                del p3
+            try:        # the literal reference-shaped call: repeat_kv-expanded K/V [1,32,L,128]
+                xin = make_inputs(cfg, dev, rank_seed(rank), expanded=True)
+                extra["tokens_per_s_batch_expanded_kv_as_reference_passes"] = quick([Prompt(cfg, dev, a.tie_mode, "batch", xin, ks)])
+                del xin
             except Exception as e:
                 extra["expanded_kv_error"] = str(e)
+            try:        # what the patched forward pays per prompt on the host side as well: PrefillBatch.add x 32 (window-Q copies,
+                #         layout keys) + grouped flushes (plan building, output allocation into the cache layers, library calls)
+                from kvcache_factory_amd import pyramidkv_utils as pu
+                from kvcache_factory_amd.cache import CompressedDynamicLayer
+                cl = {"snapkv": pu.SnapKVCluster, "pyramidkv": pu.PyramidKVCluster}[cfg["method"]]
+                kw = dict(window_size=cfg["W"], max_capacity_prompt=cfg["cap"], kernel_size=cfg["kernel"], pooling=cfg["pooling"])
+                clusters = [cl(num_hidden_layers=LAYERS, layer_idx=l, **kw) if cfg["method"] == "pyramidkv" else cl(**kw) for l in range(LAYERS)]
+                old = pu.TIE_MODE
+                pu.TIE_MODE = a.tie_mode
+
+                def host_prompt(qkv):
+                    pb = pu.PrefillBatch()
+                    layers = [CompressedDynamicLayer() for _ in range(LAYERS)]
+                    for l, (q, k, v) in enumerate(qkv):
+                        pb.add(clusters[l], k, q, v, lambda kc, vc, layer=layers[l]: layer.prefill(kc, vc, cfg["L"]), tag=layers[l],
+                               alloc=layers[l].reserve)
+                        if len(pb) >= pu.GROUP_LAYERS > 0:
+                            pb.flush(overlap=True)
+                    if len(pb):
+                        pb.flush(overlap=True)
+                    pb.settle()
+                    return layers
+                for _ in range(3):
+                    host_prompt(inputs[0])
+                torch.cuda.synchronize(dev)
+                n_h = max(10, per_step // 2)
+                t0 = time.perf_counter()
+                for i in range(n_h):
+                    host_prompt(inputs[i % n_sets])
+                torch.cuda.synchronize(dev)
+                extra["tokens_per_s_through_PrefillBatch_host_path"] = n_h * cfg["L"] * LAYERS / (time.perf_counter() - t0)
+                extra["PrefillBatch_group_layers"] = pu.GROUP_LAYERS
+                pu.TIE_MODE = old
+            except Exception as e:
+                extra["host_path_error"] = repr(e)
             out["extras"] = extra
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, dev=dev)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define KVC_VERSION 2
+#define KVC_VERSION 3
 
 typedef enum kvc_status {
     KVC_OK = 0,
@@ -64,7 +64,9 @@ typedef enum kvc_dot_mode {
                                   oracle, and the arithmetic the reference's fp16/fp32 GEMM was measured to use */
     KVC_DOT_MFMA16 = 1         /* packed bf16/fp16 16-deep MFMA (16x less matrix time; fp32 inputs fall back to EXACT).
                                   Tolerance mode: a logit may differ from EXACT by 1 unit in the last place (~1e-4 of
-                                  the entries), which can move a candidate across the top-k threshold. */
+                                  the entries), which can move a candidate across the top-k threshold.  H2O: two
+                                  recomputing passes with no logit matrix (workspace: two floats per query row), hardware
+                                  exp and fp32 sums in tile order — pooled scores within 1 unit in the last place. */
 } kvc_dot_mode;
 
 typedef struct kvc_params {
@@ -88,8 +90,12 @@ typedef struct kvc_params {
                                   scoring kernels named by bit0 = K-scan (logits), bit1 = row-sum, bit2 = pool are
                                   enqueued; kvc_compress requires them 0.  Bit3 / bit4: force the two-kernel / the
                                   one-workgroup-per-head form of the softmax+pool stage (identical results; the
-                                  library picks by the number of heads x items otherwise). */
-    int32_t dot_mode;          /* kvc_dot_mode (SnapKV / PyramidKV scan only; H2O is always EXACT) */
+                                  library picks by the number of heads x items otherwise).  Bit5 / bit6
+                                  (kvc_compress_batch, timing only): skip the scoring kernels / skip scoring and selection
+                                  and reuse what the previous identical call left in the workspace and the outputs.  Bit7
+                                  (H2O exact mode, testing): hold 512 query rows of the logit matrix at a time instead of
+                                  as many as fit in 1 GiB (identical results). */
+    int32_t dot_mode;          /* kvc_dot_mode */
     int64_t q_stride_b, q_stride_h, q_stride_l;   /* element strides of q[b][h][l][:] */
     int64_t k_stride_b, k_stride_h, k_stride_l;
     int64_t v_stride_b, v_stride_h, v_stride_l;
@@ -130,11 +136,14 @@ int kvc_compress(const kvc_params* p, const void* q, const void* k, const void* 
  * small per-call kernels stop being launch-latency bound.  The arrays are HOST arrays of DEVICE
  * pointers (they are copied into the kernel arguments; nothing is staged on the device).  idx_out / scores_out may be
  * NULL, as may their entries.  Results are identical to n_items kvc_compress calls.
+ * out_stride_h_per_item: NULL (every item uses p->out_stride_h) or n_items head strides in elements, one per item,
+ * 0 = dense — each layer's decode cache sized for its own budget (PyramidKV's layers differ by 14x at 8k).
  * Workspace: kvc_workspace_bytes_batch(). */
 size_t kvc_workspace_bytes_batch(const kvc_params* p, int n_items, const int32_t* k_per_item);
 int kvc_compress_batch(const kvc_params* p, int n_items, const int32_t* k_per_item,
                        const void* const* q, const void* const* k, const void* const* v,
                        void* const* k_out, void* const* v_out, int64_t* const* idx_out, void* const* scores_out,
+                       const int64_t* out_stride_h_per_item,
                        void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* Stage entry points (same kernels kvc_compress enqueues), exposed so parity can be pinned stage by stage. */
@@ -143,7 +152,10 @@ int kvc_compress_batch(const kvc_params* p, int n_items, const int32_t* k_per_it
 int kvc_scores(const kvc_params* p, const void* q, const void* k, void* scores_out,
                void* workspace, size_t workspace_bytes, void* hip_stream);
 
-/* A7: idx_out[b][h][0..k) = topk(scores[b][h][0..L-W), k).indices (:334). */
+/* A7: idx_out[b][h][0..k) = topk(scores[b][h][0..L-W), k).indices (:334).
+ * Workspace: kvc_select_workspace_bytes(p) bytes, 256-byte aligned (0 for most shapes: only tie_mode torch_cpu in its
+ * nth_element regime, k*64 > L-W, keeps position lists — and arrays that do not fit in LDS — there). */
+size_t kvc_select_workspace_bytes(const kvc_params* p);
 int kvc_select(const kvc_params* p, const void* scores, int64_t* idx_out,
                void* workspace, size_t workspace_bytes, void* hip_stream);
 

@@ -22,7 +22,8 @@ DOT_MODES = {"exact": DOT_EXACT, "mfma16": DOT_MFMA16}
 DOT_MODE = os.environ.get("KVC_DOT_MODE", "exact")      # default of every helper below
 
 EXPORTS = ("kvc_version", "kvc_last_error", "kvc_workspace_bytes", "kvc_compress", "kvc_scores", "kvc_select",
-           "kvc_gather", "kvc_pyramid_k", "kvc_workspace_layout", "kvc_workspace_bytes_batch", "kvc_compress_batch")
+           "kvc_gather", "kvc_pyramid_k", "kvc_workspace_layout", "kvc_workspace_bytes_batch", "kvc_compress_batch",
+           "kvc_select_workspace_bytes")
 
 
 class KvcError(RuntimeError):
@@ -66,7 +67,9 @@ def lib():
         L.kvc_workspace_layout.argtypes = [pp, ctypes.POINTER(sz * 3)]
         L.kvc_workspace_bytes_batch.argtypes = [pp, ctypes.c_int, vp]
         L.kvc_workspace_bytes_batch.restype = sz
-        L.kvc_compress_batch.argtypes = [pp, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+        L.kvc_compress_batch.argtypes = [pp, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+        L.kvc_select_workspace_bytes.argtypes = [pp]
+        L.kvc_select_workspace_bytes.restype = sz
         _lib = L
     return _lib
 
@@ -82,6 +85,26 @@ def _ptr(t):
 
 def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _one_device(*ts):
+    """Every tensor of a call lives on ONE GPU; returns it.  (HF device_map="auto" puts layers on different GPUs,
+    run_longbench.py:390: each layer's call then runs on that layer's device — see _call.)"""
+    devs = {t.device for t in ts if t is not None}
+    if len(devs) != 1:
+        raise RuntimeError(f"kvcache_factory_amd: the tensors of one call must share one device, got {sorted(map(str, devs))}")
+    return next(iter(devs))
+
+
+def _call(dev, fn, *args):
+    """Run a library entry point with `dev` as the CURRENT HIP device.  The library enqueues on the stream it is handed —
+    torch's default stream has handle 0 on every device, which HIP resolves against the current device — and raises
+    kernel attributes (hipFuncSetAttribute) for the current device, so a layer living on cuda:1 while cuda:0 is current
+    must switch first (the reference gets this for free from torch's own per-op device guards)."""
+    if torch.cuda.current_device() == dev.index:
+        return fn(*args)
+    with torch.cuda.device(dev):
+        return fn(*args)
 
 
 _workspaces = {}
@@ -158,7 +181,7 @@ def compress(method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", 
     k, v = _last_dim_contig(k), _last_dim_contig(v)
     if q is not None:
         q = _last_dim_contig(q)
-    dev = k.device
+    dev = _one_device(q, k, v, *(out if out is not None else ()))
     if method == STREAMINGLLM:
         hq = n_q_heads if n_q_heads is not None else (q.shape[1] if q is not None else k.shape[1])
         p = make_params(method, None, k, v, window, n_keep, kernel_size, None, tie_mode)
@@ -176,8 +199,8 @@ def compress(method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", 
     if nbytes == 0 and scoring:
         raise KvcError(ERR_INVALID, lib().kvc_last_error().decode())
     ws = workspace(dev, nbytes) if nbytes else None
-    _check(lib().kvc_compress(ctypes.byref(p), _ptr(qq), _ptr(k), _ptr(v), _ptr(k_out), _ptr(v_out), _ptr(idx),
-                              _ptr(sc), _ptr(ws), nbytes, _stream(dev)))
+    _check(_call(dev, lib().kvc_compress, ctypes.byref(p), _ptr(qq), _ptr(k), _ptr(v), _ptr(k_out), _ptr(v_out), _ptr(idx),
+                 _ptr(sc), _ptr(ws), nbytes, _stream(dev)))
     out = [k_out[:, :, :n_keep + window], v_out[:, :, :n_keep + window]]
     if return_indices:
         if not scoring:
@@ -189,20 +212,21 @@ def compress(method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", 
 
 
 def scores(method, q, k, window, kernel_size=5, pooling="avgpool", want_intermediates=False, dot_mode=None,
-           softmax_path=None):
+           softmax_path=None, debug_mask=0):
     """Stage A1-A5 only.  Returns pooled scores [bsz,Hq,L-W] (+ logits [bsz,Hq,L,W], rowmax, rowsum).
     softmax_path: None (library's choice) | "split" | "fused" — identical results (debug_stage_mask bits 3/4)."""
     _require_gpu(q, k)
     q, k = _last_dim_contig(q), _last_dim_contig(k)
     p = make_params(method, q, k, None, window, 0, kernel_size, pooling, dot_mode=dot_mode)
-    p.debug_stage_mask = {None: 0, "split": 8, "fused": 16}[softmax_path]
+    p.debug_stage_mask = {None: 0, "split": 8, "fused": 16}[softmax_path] | debug_mask
     bsz, hq, L = q.shape[0], q.shape[1], q.shape[2]
     sc = torch.empty(bsz, hq, L - window, dtype=q.dtype, device=q.device)
     nbytes = lib().kvc_workspace_bytes(ctypes.byref(p))
     if nbytes == 0:
         raise KvcError(ERR_INVALID, lib().kvc_last_error().decode())
-    ws = workspace(q.device, nbytes)
-    _check(lib().kvc_scores(ctypes.byref(p), _ptr(q), _ptr(k), _ptr(sc), _ptr(ws), nbytes, _stream(q.device)))
+    dev = _one_device(q, k)
+    ws = workspace(dev, nbytes)
+    _check(_call(dev, lib().kvc_scores, ctypes.byref(p), _ptr(q), _ptr(k), _ptr(sc), _ptr(ws), nbytes, _stream(dev)))
     if not want_intermediates:
         return sc
     offs = (ctypes.c_size_t * 3)()
@@ -226,11 +250,10 @@ def select(scores_t, n_keep, tie_mode="torch_cpu"):
     p.pooling = POOL_NONE
     p.tie_mode = TIE_MODES[tie_mode] if isinstance(tie_mode, str) else tie_mode
     idx = torch.empty(scores_t.shape[0], scores_t.shape[1], n_keep, dtype=torch.int64, device=scores_t.device)
-    ws, nbytes = None, 0
-    if p.tie_mode == TIES_TORCH_CPU:      # the exact path may keep its (key, index) array in the workspace
-        nbytes = scores_t.shape[0] * scores_t.shape[1] * (scores_t.shape[2] + scores_t.shape[2] // 2 + 2) * 8 + 256
-        ws = workspace(scores_t.device, nbytes)
-    _check(lib().kvc_select(ctypes.byref(p), _ptr(scores_t), _ptr(idx), _ptr(ws), nbytes, _stream(scores_t.device)))
+    nbytes = lib().kvc_select_workspace_bytes(ctypes.byref(p))     # 0 unless the exact tie mode keeps lists / arrays there
+    ws = workspace(scores_t.device, nbytes) if nbytes else None
+    _check(_call(scores_t.device, lib().kvc_select, ctypes.byref(p), _ptr(scores_t), _ptr(idx), _ptr(ws), nbytes,
+                 _stream(scores_t.device)))
     return idx
 
 
@@ -242,8 +265,9 @@ def gather(src, idx, window, n_q_heads):
     p = make_params(SNAPKV, None, src, None, window, n_keep, 1, None)
     p.n_q_heads = n_q_heads
     out = torch.empty(src.shape[0], n_q_heads, n_keep + window, src.shape[3], dtype=src.dtype, device=src.device)
-    _check(lib().kvc_gather(ctypes.byref(p), _ptr(src), src.stride(0), src.stride(1), src.stride(2),
-                            _ptr(idx.contiguous() if idx is not None else None), _ptr(out), _stream(src.device)))
+    dev = _one_device(src, idx)
+    _check(_call(dev, lib().kvc_gather, ctypes.byref(p), _ptr(src), src.stride(0), src.stride(1), src.stride(2),
+                 _ptr(idx.contiguous() if idx is not None else None), _ptr(out), _stream(dev)))
     return out
 
 
@@ -262,7 +286,7 @@ class CompressPlan:
         _require_gpu(q, k, v)
         self.q = _last_dim_contig(q) if q is not None else None
         self.k, self.v = _last_dim_contig(k), _last_dim_contig(v)
-        dev = self.k.device
+        dev = _one_device(self.q, self.k, self.v)
         scoring = method != STREAMINGLLM
         if scoring:
             self.p = make_params(method, self.q, self.k, self.v, window, n_keep, kernel_size, pooling, tie_mode, dot_mode)
@@ -286,7 +310,7 @@ class CompressPlan:
         self._fn = lib().kvc_compress
 
     def run(self, stream=None):
-        rc = self._fn(*self._args, stream if stream is not None else _stream(self.dev))
+        rc = _call(self.dev, self._fn, *self._args, stream if stream is not None else _stream(self.dev))
         if rc:
             _check(rc)
         return self.k_out, self.v_out
@@ -326,16 +350,16 @@ class BatchPlan:
             q_off = (k.shape[2] - window) * q.stride(2) * q.element_size()
         else:
             assert q_rows == "all" and (not scoring or q.shape[2] == k.shape[2])
-        dev = k.device
+        dev = _one_device(*[t for it in self.items for t in it], *[t for o in (outs or ()) for t in o])
         bsz, hq, D = k.shape[0], self.p.n_q_heads, k.shape[3]
+        self._strides = None
         if outs is None:
             self.k_out = [torch.empty(bsz, hq, kk + window, D, dtype=k.dtype, device=dev) for kk in keeps]
             self.v_out = [torch.empty_like(t) for t in self.k_out]
             kbufs, vbufs = self.k_out, self.v_out
-        else:                                              # caller's buffers, one (k_buf, v_buf) per item, one head stride
+        else:                              # caller's buffers, one (k_buf, v_buf) per item, each with its own head stride
             trip = [_out_views(o, bsz, hq, kk + window, D, k.dtype, dev) for o, kk in zip(outs, keeps)]
-            assert len({t[2] for t in trip}) == 1, "out buffers must share one head stride"
-            self.p.out_stride_h = trip[0][2]
+            self._strides = (ctypes.c_int64 * n)(*[t[2] for t in trip])
             kbufs, vbufs = [t[0] for t in trip], [t[1] for t in trip]
             self.k_out = [t[0][:, :, :kk + window] for t, kk in zip(trip, keeps)]
             self.v_out = [t[1][:, :, :kk + window] for t, kk in zip(trip, keeps)]
@@ -354,10 +378,15 @@ class BatchPlan:
         self.ws = workspace(dev, self.nbytes) if self.nbytes else None
         self.dev, self.n = dev, n
 
+    def call(self, params=None, scores_out=None, stream=None):
+        """The raw kvc_compress_batch call of this plan: `params` overrides the parameter block (e.g. debug_stage_mask for
+        profiling one kernel), `scores_out` is a ctypes array of per-item score buffers; returns the status code."""
+        return _call(self.dev, lib().kvc_compress_batch, ctypes.byref(params if params is not None else self.p), self.n,
+                     self._keep, self._q, self._k, self._v, self._ko, self._vo, self._ix, scores_out, self._strides,
+                     _ptr(self.ws), self.nbytes, stream if stream is not None else _stream(self.dev))
+
     def run(self, stream=None):
-        rc = lib().kvc_compress_batch(ctypes.byref(self.p), self.n, self._keep, self._q, self._k, self._v, self._ko,
-                                      self._vo, self._ix, None, _ptr(self.ws), self.nbytes,
-                                      stream if stream is not None else _stream(self.dev))
+        rc = self.call(stream=stream)
         if rc:
             _check(rc)
         return self.k_out, self.v_out

@@ -6,8 +6,9 @@
     prefill  (this layer's cache is empty):                # reference: key_states.shape[-2] == kv_seq_len (:283)
         Kc, Vc = self.kv_cluster.update_kv(K, Q, V, attention_mask, num_key_value_groups)       (:285)
         cache <- Kc, Vc (H_q heads, cap tokens); true length remembered                         (:286,:290)
-        [default, pyramidkv_utils.BATCH_LAYERS: the call is parked in a PrefillBatch and the LAST layer runs all of
-         them as one kvc_compress_batch — same bytes, one launch of each kernel per prompt instead of one per layer]
+        [default, pyramidkv_utils.BATCH_LAYERS: the call is parked in a PrefillBatch; every GROUP_LAYERS-th layer runs the
+         parked ones as one kvc_compress_batch on a side stream while the model goes on — same bytes, one launch of each
+         kernel per group instead of one per layer, off the model's critical path]
         attention of THIS step runs over the uncompressed K, V                                  (:306-313)
     decode   : append the new token (expanded to H_q heads) and attend over cap + t tokens      (:287-289)
 
@@ -100,14 +101,27 @@ def make_forward(method, apply_rotary_pos_emb, eager_attention_forward, repeat_k
                         kc = repeat_kv(key_states, self.num_key_value_groups)    # reference caches the expanded K/V
                         vc = repeat_kv(value_states, self.num_key_value_groups)
                     layer.prefill(kc, vc, q_len)
-                if len(pending) and self.layer_idx == self.config.num_hidden_layers - 1:
-                    pending.flush()                                          # all layers of the prompt in ONE call
+                last = self.layer_idx == self.config.num_hidden_layers - 1
+                if len(pending) and (last or (pu.GROUP_LAYERS > 0 and len(pending) >= pu.GROUP_LAYERS)):
+                    pending.flush(overlap=True)                              # a group of layers in ONE call, beside the
+                if last:                                                     # model's prefill of the following layers
+                    pending.settle()
                 # this step's attention sees the full, uncompressed K/V (H_kv heads; the interface expands)
             else:                                                            # decode over the compressed cache
+                pending.settle()
                 key_states = repeat_kv(key_states, self.num_key_value_groups)
                 value_states = repeat_kv(value_states, self.num_key_value_groups)
                 key_states, value_states = past_key_values.update(key_states, value_states, self.layer_idx)
                 attn_module = _OneGroup(self)
+                # transformers builds ONE mask per forward from the first layer's lengths; layers store different numbers
+                # of tokens (PyramidKV) and eager attention no longer cuts the mask to the keys: keep its last kv columns
+                # (the new tokens' causal block sits at the end; every stored prefix token is visible to a decode step)
+                if torch.is_tensor(attention_mask) and attention_mask.dim() == 4 and \
+                        attention_mask.shape[-1] != key_states.shape[-2]:
+                    if attention_mask.shape[-1] < key_states.shape[-2]:
+                        raise RuntimeError(f"attention mask covers {attention_mask.shape[-1]} keys, the compressed cache of "
+                                           f"layer {self.layer_idx} holds {key_states.shape[-2]}")
+                    attention_mask = attention_mask[..., -key_states.shape[-2]:]
 
         attention_interface: Callable = ALL_ATTENTION_FUNCTIONS.get_interface(
             self.config._attn_implementation, eager_attention_forward)

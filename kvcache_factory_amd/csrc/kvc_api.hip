@@ -28,6 +28,7 @@ inline bool scoring(int method) { return method == KVC_SNAPKV || method == KVC_P
 struct Layout {
     size_t logits, pmax, psum, rowmax, rowsum, scores, idx, exact, total;   // H2O: logits = S [L][L], rowmax/rowsum = [L] per head
     int n_tiles, n_chunks;
+    int h2o_rows;      // H2O exact mode: query rows of S in flight; 0 in fast mode (no S)
 };
 
 // Validation shared by every entry point.  `need_q`: the call reads q/k for scoring.
@@ -97,10 +98,14 @@ Layout carve(const kvc_params* p, int n_items = 1) {
     size_t off = 0;
     if (scoring(p->method)) {
         const size_t R = p->method == KVC_H2O ? L : W;     // query rows that score
-        l.logits = off; off = align_up(off + heads * L * R * es, 256);
+        const bool h2o_fast = p->method == KVC_H2O && p->dot_mode == KVC_DOT_MFMA16 && p->dtype != KVC_FP32;
+        l.h2o_rows = (p->method == KVC_H2O && !h2o_fast) ? kvc::h2o_chunk_rows((int)heads, (int)L, (int)es) : 0;
+        if (l.h2o_rows > 512 && (p->debug_stage_mask & 128)) l.h2o_rows = 512;      // testing aid: several chunks at small L
+        // logits: [h][L][W] for the window methods; H2O exact: the chunk [h][h2o_rows][L]; H2O fast: nothing
+        l.logits = off; off = align_up(off + (p->method == KVC_H2O ? heads * (size_t)l.h2o_rows * L * es : heads * L * R * es), 256);
         l.pmax = off;   off = align_up(off + (p->method == KVC_H2O ? 0 : heads * (size_t)l.n_tiles * W * 4), 256);
         // H2O: column sums of every 256-row block (+ one slot for the leftover rows), fp32, columns padded to even
-        l.psum = off;   off = align_up(off + (p->method == KVC_H2O ? heads * (size_t)(l.n_chunks + 1) * ((n + 1) & ~(size_t)1) * 4 : 0), 256);
+        l.psum = off;   off = align_up(off + ((p->method == KVC_H2O && !h2o_fast) ? heads * (size_t)(l.n_chunks + 1) * ((n + 1) & ~(size_t)1) * 4 : 0), 256);
         l.rowmax = off; off = align_up(off + heads * R * 4, 256);
         l.rowsum = off; off = align_up(off + heads * R * 4, 256);
         l.scores = off; off = align_up(off + heads * n * es, 256);
@@ -132,6 +137,7 @@ struct Items {
     void* k_out[kvc::KVC_MAX_ITEMS]; void* v_out[kvc::KVC_MAX_ITEMS];
     void* scores[kvc::KVC_MAX_ITEMS]; int64_t* idx[kvc::KVC_MAX_ITEMS];
     int keep[kvc::KVC_MAX_ITEMS];
+    int64_t out_stride_h[kvc::KVC_MAX_ITEMS];       // elements between output heads, 0 = dense
     int k_max;
 };
 
@@ -143,6 +149,8 @@ int enqueue_scores(const kvc_params* p, const Layout& l, const Items& it, char* 
             kvc::H2OArgs h;
             h.q = it.q[i]; h.k = it.k[i];
             h.S = w + l.logits;
+            h.row0 = 0; h.rows = p->q_len; h.s_rows = l.h2o_rows;
+            h.fast = l.h2o_rows == 0 ? 1 : 0;
             h.rowmax = reinterpret_cast<float*>(w + l.rowmax);
             h.rinv = reinterpret_cast<float*>(w + l.rowsum);
             h.part = reinterpret_cast<float*>(w + l.psum);
@@ -192,6 +200,7 @@ kvc::GatherArgs gather_args(const kvc_params* p, const Items& it, int which, boo
         g.out.p[i] = which ? it.v_out[i] : it.k_out[i];
         g.idx.p[i] = use_idx ? it.idx[i] : nullptr;
         g.k.v[i] = it.keep[i];
+        g.out_head_bytes.v[i] = it.out_stride_h[i] * esize_of(p->dtype);
     }
     g.n_items = it.n; g.k_max = it.k_max;
     g.stride_b = which ? p->v_stride_b : p->k_stride_b;
@@ -201,7 +210,6 @@ kvc::GatherArgs gather_args(const kvc_params* p, const Items& it, int which, boo
     g.q_len = p->q_len; g.window = p->window;
     g.esize = esize_of(p->dtype);
     g.row_bytes = p->head_dim * g.esize;
-    g.out_head_bytes = p->out_stride_h * g.esize;
     return g;
 }
 
@@ -262,11 +270,13 @@ int run_items(const kvc_params* p, Items& it, void* workspace, size_t workspace_
         if (it.keep[i] < 0 || it.keep[i] > p->q_len - p->window) return fail(KVC_ERR_INVALID, "k=%d outside [0, q_len-window] (item %d)", it.keep[i], i);
         if (it.keep[i] > it.k_max) it.k_max = it.keep[i];
     }
-    if (p->out_stride_h != 0) {
-        if (p->out_stride_h < (int64_t)(it.k_max + p->window) * p->head_dim)
-            return fail(KVC_ERR_INVALID, "out_stride_h %lld smaller than (k + window) * head_dim = %lld", (long long)p->out_stride_h,
-                        (long long)(it.k_max + p->window) * p->head_dim);
-        if ((p->out_stride_h * es) % 16) return fail(KVC_ERR_ALIGNMENT, "out_stride_h not a multiple of 16 bytes");
+    for (int i = 0; i < it.n; ++i) {
+        const int64_t os = it.out_stride_h[i];
+        if (os == 0) continue;
+        if (os < (int64_t)(it.keep[i] + p->window) * p->head_dim)
+            return fail(KVC_ERR_INVALID, "out_stride_h %lld smaller than (k + window) * head_dim = %lld (item %d)", (long long)os,
+                        (long long)(it.keep[i] + p->window) * p->head_dim, i);
+        if ((os * es) % 16) return fail(KVC_ERR_ALIGNMENT, "out_stride_h not a multiple of 16 bytes (item %d)", i);
     }
     if (!scoring(p->method)) {
         for (int i = 0; i < it.n; ++i)
@@ -297,8 +307,14 @@ int run_items(const kvc_params* p, Items& it, void* workspace, size_t workspace_
     }
     if (int rc = check_strides("q", es, p->q_stride_b, p->q_stride_h, p->q_stride_l, it.q[0])) return rc;
     if (any_zero && it.n > 1) return fail(KVC_ERR_UNSUPPORTED, "a batch needs k >= 1 for every item");
-    if (int rc = enqueue_scores(p, l, it, ws, st)) return rc;
-    if ((p->debug_stage_mask & 7) != 0) return KVC_OK;      // profiling aid: only the selected scoring kernels
+    const int dbg = p->debug_stage_mask;
+    if (!(dbg & 96))                                         // profiling aid bits 5 / 6: scores (and indices) of the previous run
+        if (int rc = enqueue_scores(p, l, it, ws, st)) return rc;
+    if ((dbg & 7) != 0) return KVC_OK;                       // profiling aid: only the selected scoring kernels
+    if (dbg & 64) {                                          // ... only the gather
+        const kvc::GatherArgs gk = gather_args(p, it, 0, true), gv = gather_args(p, it, 1, true);
+        return enqueue_gather(&gk, &gv, st);
+    }
     if (it.k_max == 0) {                                     // nothing to select: only the window tail is kept
         const kvc::GatherArgs gk = gather_args(p, it, 0, false), gv = gather_args(p, it, 1, false);
         return enqueue_gather(&gk, &gv, st);
@@ -385,6 +401,13 @@ __attribute__((visibility("default"))) int kvc_scores(const kvc_params* p, const
     return enqueue_scores(p, l, it, static_cast<char*>(workspace), static_cast<hipStream_t>(hip_stream));
 }
 
+__attribute__((visibility("default"))) size_t kvc_select_workspace_bytes(const kvc_params* p) {
+    if (validate(p, false) != KVC_OK) return 0;
+    g_err[0] = 0;
+    if (p->tie_mode != KVC_TIES_TORCH_CPU || p->k == 0) return 0;
+    return align_up(kvc::select_exact_scratch_bytes(p->bsz * p->n_q_heads, p->q_len - p->window, p->k), 256);
+}
+
 __attribute__((visibility("default"))) int kvc_select(const kvc_params* p, const void* scores, int64_t* idx_out,
                                                       void* workspace, size_t workspace_bytes, void* hip_stream) {
     if (int rc = validate(p, false)) return rc;
@@ -415,6 +438,7 @@ __attribute__((visibility("default"))) int kvc_gather(const kvc_params* p, const
     Items it;
     std::memset(&it, 0, sizeof(it));
     it.n = 1; it.k[0] = src; it.k_out[0] = out; it.idx[0] = const_cast<int64_t*>(idx); it.keep[0] = p->k; it.k_max = p->k;
+    it.out_stride_h[0] = p->out_stride_h;
     kvc_params ps = *p;
     ps.k_stride_b = stride_b; ps.k_stride_h = stride_h; ps.k_stride_l = stride_l;
     const kvc::GatherArgs g = gather_args(&ps, it, 0, idx != nullptr);
@@ -430,15 +454,15 @@ __attribute__((visibility("default"))) int kvc_compress(const kvc_params* p, con
     std::memset(&it, 0, sizeof(it));
     it.n = 1;
     it.q[0] = q; it.k[0] = k; it.v[0] = v; it.k_out[0] = k_out; it.v_out[0] = v_out;
-    it.idx[0] = idx_out; it.scores[0] = scores_out; it.keep[0] = p->k;
+    it.idx[0] = idx_out; it.scores[0] = scores_out; it.keep[0] = p->k; it.out_stride_h[0] = p->out_stride_h;
     return run_items(p, it, workspace, workspace_bytes, static_cast<hipStream_t>(hip_stream));
 }
 
 __attribute__((visibility("default"))) int kvc_compress_batch(const kvc_params* p, int n_items, const int32_t* k_per_item,
                                                               const void* const* q, const void* const* k, const void* const* v,
                                                               void* const* k_out, void* const* v_out, int64_t* const* idx_out,
-                                                              void* const* scores_out, void* workspace, size_t workspace_bytes,
-                                                              void* hip_stream) {
+                                                              void* const* scores_out, const int64_t* out_stride_h_per_item,
+                                                              void* workspace, size_t workspace_bytes, void* hip_stream) {
     if (int rc = validate(p, true)) return rc;
     if (n_items < 1 || !k_per_item || !k || !v || !k_out || !v_out) return fail(KVC_ERR_INVALID, "n_items >= 1 and the pointer arrays must be non-NULL");
     if (scoring(p->method) && !q) return fail(KVC_ERR_INVALID, "q array must be non-NULL for scoring methods");
@@ -454,6 +478,7 @@ __attribute__((visibility("default"))) int kvc_compress_batch(const kvc_params* 
             it.idx[i] = idx_out ? idx_out[base + i] : nullptr;
             it.scores[i] = scores_out ? scores_out[base + i] : nullptr;
             it.keep[i] = k_per_item[base + i];
+            it.out_stride_h[i] = out_stride_h_per_item ? out_stride_h_per_item[base + i] : p->out_stride_h;
         }
         if (int rc = run_items(p, it, workspace, workspace_bytes, st)) return rc;
     }

@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherPair pr) {
     const int64_t esz = a.esize;
     const char* src = reinterpret_cast<const char*>(a.src.p[item]) +
         ((int64_t)b * a.stride_b + (int64_t)(h / a.group) * a.stride_h + srow * a.stride_l) * esz + c * 16;
-    const int64_t head_bytes = a.out_head_bytes ? a.out_head_bytes : (int64_t)cap * a.row_bytes;
+    const int64_t ohb = a.out_head_bytes.v[item];
+    const int64_t head_bytes = ohb ? ohb : (int64_t)cap * a.row_bytes;
     char* dst = reinterpret_cast<char*>(const_cast<void*>(a.out.p[item])) + (int64_t)hb * head_bytes + (int64_t)t * a.row_bytes + c * 16;
     *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
 }

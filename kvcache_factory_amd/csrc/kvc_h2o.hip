@@ -68,8 +68,8 @@ __global__ __launch_bounds__(256) void h2o_logits_kernel(const H2OArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
     const int hb = blockIdx.y, b = hb / a.n_q_heads, h = hb % a.n_q_heads, g = h / a.group;
     const int L = a.q_len, W = a.window;
-    const int r0 = (blockIdx.x * 4 + wave) * 32;
-    if (r0 >= L) return;                                   // whole wave idle (no barriers below)
+    const int r0 = a.row0 + (blockIdx.x * 4 + wave) * 32;
+    if (r0 >= L || r0 >= a.row0 + a.rows) return;          // whole wave idle (no barriers below)
     char* const buf = smem + wave * (2 * 32 * ROWP);
     const int n_t = (L + 31) / 32;
     const float sqrt_d = a.sqrt_d;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void h2o_logits_kernel(const H2OArgs a) {
     float rmax[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) rmax[e] = -__builtin_inff();
-    raw* const Sh = reinterpret_cast<raw*>(a.S) + (int64_t)hb * L * L;
+    raw* const Sh = reinterpret_cast<raw*>(a.S) + ((int64_t)hb * a.s_rows - a.row0) * L;   // row r of the chunk at Sh + r * L
     int cur = 0;
     for (int tile = 0; tile < n_t; ++tile) {
         if (tile + 1 < n_t) issue(tile + 1, st);
@@ -178,10 +178,10 @@ __global__ __launch_bounds__(256) void h2o_rowsum_kernel(const H2OArgs a) {
     typedef typename Dt<DT>::raw raw;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hb = blockIdx.y, L = a.q_len;
-    const int r = (blockIdx.x * 4 + wave) * 4 + (lane >> 4);
+    const int r = a.row0 + (blockIdx.x * 4 + wave) * 4 + (lane >> 4);
     const int l = lane & 15;
-    const bool valid = r < L;
-    const raw* row = reinterpret_cast<const raw*>(a.S) + ((int64_t)hb * L + (valid ? r : 0)) * L;
+    const bool valid = r < L && r < a.row0 + a.rows;
+    const raw* row = reinterpret_cast<const raw*>(a.S) + ((int64_t)hb * a.s_rows + (valid ? r - a.row0 : 0)) * L;
     const float m = valid ? a.rowmax[(int64_t)hb * L + r] : 0.0f;
     float s;
     if (L < 16) {                                         // vec::reduce_all "slow path": plain left-to-right sum
@@ -218,10 +218,10 @@ __global__ __launch_bounds__(256) void h2o_rowsum_wide_kernel(const H2OArgs a) {
     typedef typename Dt<DT>::raw raw;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hb = blockIdx.y, L = a.q_len;
-    const int r = (blockIdx.x * 4 + wave) * 32 + (lane >> 1);
+    const int r = a.row0 + (blockIdx.x * 4 + wave) * 32 + (lane >> 1);
     const int half = lane & 1;
-    const bool valid = r < L;
-    const raw* row = reinterpret_cast<const raw*>(a.S) + ((int64_t)hb * L + (valid ? r : 0)) * L + 8 * half;
+    const bool valid = r < L && r < a.row0 + a.rows;
+    const raw* row = reinterpret_cast<const raw*>(a.S) + ((int64_t)hb * a.s_rows + (valid ? r - a.row0 : 0)) * L + 8 * half;
     const float m = valid ? a.rowmax[(int64_t)hb * L + r] : 0.0f;
     const f32x2 m2 = {m, m};
     f32x2 acc[4];
@@ -331,12 +331,12 @@ __global__ __launch_bounds__(256) void h2o_colsum_wide_kernel(const H2OArgs a) {
 // 32x the parallelism of one thread walking all L rows (which ran at two waves per SIMD).
 template <int DT>
 __global__ __launch_bounds__(256) void h2o_colpart_kernel(const H2OArgs a) {
-    const int hb = blockIdx.y, g = blockIdx.z, L = a.q_len, n = L - a.window;
+    const int hb = blockIdx.y, g = blockIdx.z + a.row0 / 256, L = a.q_len, n = L - a.window;   // g: 256-row block of the prompt
     const int jcol = (blockIdx.x * 256 + threadIdx.x) * 2;
     if (jcol >= n) return;
     const int n_pad = (n + 1) & ~1, n_blk = (L + 255) / 256;
     const int r0 = g * 256, r1 = r0 + 256 < L ? r0 + 256 : L, full = L - (L % 16);
-    const uint32_t* S = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.S) + ((int64_t)hb * L * L + jcol) * 2);
+    const uint32_t* S = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.S) + (((int64_t)hb * a.s_rows - a.row0) * L + jcol) * 2);
     const float* m = a.rowmax + (int64_t)hb * L;
     const float* ri = a.rinv + (int64_t)hb * L;
     const int64_t pitch = L / 2;
@@ -404,32 +404,378 @@ __global__ __launch_bounds__(256) void h2o_colsum_kernel(const H2OArgs a) {
     reinterpret_cast<raw*>(a.scores)[(int64_t)hb * n + jcol] = Dt<DT>::st(rnd<DT>(cs.result()));
 }
 
+// One column per thread forms of the two kernels above (any dtype, any L / W parity): used when the prompt is processed in
+// row chunks and the pair form does not apply.
+template <int DT>
+__global__ __launch_bounds__(256) void h2o_colpart1_kernel(const H2OArgs a) {
+    typedef typename Dt<DT>::raw raw;
+    const int hb = blockIdx.y, g = blockIdx.z + a.row0 / 256, L = a.q_len, n = L - a.window;
+    const int jcol = blockIdx.x * 256 + threadIdx.x;
+    if (jcol >= n) return;
+    const int n_pad = (n + 1) & ~1, n_blk = (L + 255) / 256;
+    const int r0 = g * 256, r1 = r0 + 256 < L ? r0 + 256 : L, full = L - (L % 16);
+    const raw* S = reinterpret_cast<const raw*>(a.S) + ((int64_t)hb * a.s_rows - a.row0) * L + jcol;
+    const float* m = a.rowmax + (int64_t)hb * L;
+    const float* ri = a.rinv + (int64_t)hb * L;
+    float a0 = 0.0f, a1 = 0.0f;
+    for (int r = r0; r < r1; ++r) {
+        a0 = a0 + rnd<DT>(exp_u20(Dt<DT>::ld(S[(int64_t)r * L]) - m[r]) * ri[r]);
+        if (((r + 1) & 15) == 0 && r + 1 <= full) { a1 = a1 + a0; a0 = 0.0f; }
+    }
+    a.part[((int64_t)hb * (n_blk + 1) + g) * n_pad + jcol] = a1;
+    if (g == n_blk - 1) a.part[((int64_t)hb * (n_blk + 1) + n_blk) * n_pad + jcol] = a0;
+}
+template <int DT>
+__global__ __launch_bounds__(256) void h2o_colcomb1_kernel(const H2OArgs a) {
+    typedef typename Dt<DT>::raw raw;
+    const int hb = blockIdx.y, L = a.q_len, n = L - a.window;
+    const int jcol = blockIdx.x * 256 + threadIdx.x;
+    if (jcol >= n) return;
+    const int n_pad = (n + 1) & ~1, n_blk = (L + 255) / 256, n_complete = L / 256;
+    const float* base = a.part + (int64_t)hb * (n_blk + 1) * n_pad + jcol;
+    float a2 = 0.0f, a3 = 0.0f;
+    for (int g = 0; g < n_complete; ++g) {
+        a2 = a2 + base[(int64_t)g * n_pad];
+        if (((g + 1) & 15) == 0) { a3 = a3 + a2; a2 = 0.0f; }
+    }
+    const float a1 = n_complete < n_blk ? base[(int64_t)n_complete * n_pad] : 0.0f;
+    const float a0 = base[(int64_t)n_blk * n_pad];
+    reinterpret_cast<raw*>(a.scores)[(int64_t)hb * n + jcol] = Dt<DT>::st(rnd<DT>(((a0 + a1) + a2) + a3));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fast mode (dot_mode = KVC_DOT_MFMA16, 16-bit dtypes): no logit matrix at all.  Two passes, each recomputing Q K^T on
+// the packed 16-deep MFMA (16x the f32-input rate), written so that every reduction is lane-local:
+//   pass 1  h2o_fast_stats_kernel  : S^T tiles (MFMA rows = keys, columns = query rows): a lane owns ONE query row and
+//           sixteen keys of each tile, keeps a running maximum and a rescaled running sum of exponentials for it (online
+//           softmax; the two lanes of a row are combined once at the end).  Output per row: -max * log2(e) and 1 / sum.
+//   pass 2  h2o_fast_colsum_kernel : S tiles (rows = query rows, columns = keys): a lane owns ONE key column and sixteen
+//           rows of each tile; p = round(exp2(x * log2(e) - max * log2(e)) * rinv) summed over all row tiles in registers.
+// Workspace: two floats per query row.  The arithmetic is the reference's up to (a) the MFMA's internal accumulation order
+// (tools/mfma_probe.hip), (b) exp by v_exp_f32 instead of torch's polynomial, (c) fp32 sums in tile order instead of
+// torch's 16-lane / cascade orders: a TOLERANCE mode (tests/test_gpu_parity.py::test_h2o_fast_mode_within_tolerance).
+// Workgroup -> (head, tile block) mapping: consecutive workgroup ids go to consecutive XCDs, so with the KV head
+// (pass 1) / query head (pass 2) taken from id % 8 every XCD streams ONE head's 2 MB of K (Q) through its own L2.
+// ---------------------------------------------------------------------------------------------------------
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+template <int DT> __device__ __forceinline__ f32x16 mfma_pk16(const uint4& av, const uint4& bv, f32x16 acc) {
+    if constexpr (DT == KVC_BF16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, av), __builtin_bit_cast(s16x8, bv), acc, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, av), __builtin_bit_cast(h16x8, bv), acc, 0, 0, 0);
+}
+// two values rounded to the storage dtype and widened again
+template <int DT> __device__ __forceinline__ f32x2 round2(f32x2 v) {
+    if constexpr (DT == KVC_BF16) {
+        asm volatile("" : "+v"(v));
+        const uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));     // v_cvt_pk_bf16_f32
+        return f32x2{u2f(w << 16), u2f(w & 0xffff0000u)};
+    } else {
+        return f32x2{rnd<DT>(v.x), rnd<DT>(v.y)};
+    }
+}
+// the reference's  round(round(dot) / sqrt(D))  on a pair (x / sqrt(128) as the 2-FMA division of kvc_score.hip, unguarded:
+// outside its proven range the quotient may be one fp32 ulp off — inside this mode's tolerance)
+template <int DT, int D> __device__ __forceinline__ f32x2 logit2(f32x2 acc, float c) {
+    const f32x2 r1 = round2<DT>(acc);
+    if constexpr (D == 64) {
+        return round2<DT>(r1 * (f32x2)0.125f);
+    } else {
+        const f32x2 rc = u2f(0x3db504f3u), cc = c;
+        const f32x2 q0 = r1 * rc;
+        const f32x2 r = __builtin_elementwise_fma(-q0, cc, r1);
+        return round2<DT>(__builtin_elementwise_fma(r, rc, q0));
+    }
+}
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kNeg = -1.0e30f;                            // "minus infinity" that stays finite under subtraction
+
+struct FastMap { int b, h, g, hb, blk; };
+// Workgroup id -> (batch, query head, its kv head, tile block).  Ids x, x + 8, x + 16, ... share an XCD (round-robin
+// placement, observed, speed only): the stream of ids of one XCD walks all tile blocks of ONE head (pass 1: one kv head
+// and its `group` query heads in turn; pass 2: one query head) before it moves to the next, so the head's K (or Q),
+// 2 MB at 8k, is read from HBM once and then served by that XCD's L2.
+__device__ __forceinline__ FastMap fast_map(const H2OArgs& a, int id, int n_blk, bool by_kv_head) {
+    FastMap m;
+    const int n_units = by_kv_head ? a.n_kv_heads : a.n_q_heads;      // heads that own a stream of tile blocks
+    const int per_unit = by_kv_head ? a.group : 1;                    // query heads visited per unit
+    int unit, rest;
+    if (n_units % 8 == 0) {
+        const int x = id & 7;
+        rest = id >> 3;
+        m.blk = rest % n_blk; rest /= n_blk;
+        const int qi = rest % per_unit; rest /= per_unit;
+        unit = x + 8 * (rest % (n_units / 8));
+        m.b = rest / (n_units / 8);
+        m.g = by_kv_head ? unit : unit / a.group;
+        m.h = by_kv_head ? unit * a.group + qi : unit;
+    } else {
+        m.blk = id % n_blk; rest = id / n_blk;
+        m.h = rest % a.n_q_heads;
+        m.b = rest / a.n_q_heads;
+        m.g = m.h / a.group;
+    }
+    m.hb = m.b * a.n_q_heads + m.h;
+    return m;
+}
+
+constexpr int FAST_THREADS = 256;                            // 4 waves; each owns 2 tiles (64 rows / 64 keys) of the block's 256
 template <int DT, int D>
-static int launch_h2o_t(const H2OArgs& a, hipStream_t st) {
+__global__ __launch_bounds__(FAST_THREADS, 2) void h2o_fast_stats_kernel(const H2OArgs a) {
+    constexpr int ROWB = D * 2, ROWP = ROWB + 16, NS = D / 16, CPR = ROWB / 16, CHT = 32 * CPR / FAST_THREADS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 x 32 x ROWP
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = a.q_len, W = a.window, n_t = (L + 31) / 32;
+    const FastMap fm = fast_map(a, blockIdx.x, (L + 255) / 256, true);
+    const int r0 = fm.blk * 256 + wave * 64;
+    const char* const kbase = reinterpret_cast<const char*>(a.k) + ((int64_t)fm.b * a.k_stride_b + (int64_t)fm.g * a.k_stride_h) * 2;
+    const int64_t krow_bytes = a.k_stride_l * 2;
+    uint4 bq[2][NS];                                                      // B operand: this lane's query row, chunk 2 s + kh
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int row = r0 + rt * 32 + j;
+        const char* qrow = reinterpret_cast<const char*>(a.q) +
+            ((int64_t)fm.b * a.q_stride_b + (int64_t)fm.h * a.q_stride_h + (int64_t)(row < L ? row : 0) * a.q_stride_l) * 2;
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_)
+            bq[rt][s_] = row < L ? *reinterpret_cast<const uint4*>(qrow + (2 * s_ + kh) * 16) : make_uint4(0, 0, 0, 0);
+    }
+    uint4 st[CHT];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < CHT; ++i) {
+            const int c = tid + FAST_THREADS * i, r = c / CPR, cc = c % CPR, key = t * 32 + r;
+            st[i] = key < L ? *reinterpret_cast<const uint4*>(kbase + (int64_t)key * krow_bytes + cc * 16) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](char* buf) {
+#pragma unroll
+        for (int i = 0; i < CHT; ++i) {
+            const int c = tid + FAST_THREADS * i, r = c / CPR, cc = c % CPR;
+            *reinterpret_cast<uint4*>(buf + r * ROWP + cc * 16) = st[i];
+        }
+    };
+    float mrun[2] = {kNeg, kNeg}, srun[2] = {0.0f, 0.0f};
+    const float sqrt_d = a.sqrt_d;
+    gload(0);
+    lstore(smem);
+    __syncthreads();
+    for (int t = 0; t < n_t; ++t) {
+        if (t + 1 < n_t) gload(t + 1);
+        const char* const buf = smem + (t & 1) * (32 * ROWP);
+        f32x16 acc[2];
+        acc[0] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc[1] = acc[0];
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const uint4 ak = *reinterpret_cast<const uint4*>(buf + j * ROWP + (2 * s_ + kh) * 16);   // A operand: key row j of the tile
+            acc[0] = mfma_pk16<DT>(ak, bq[0][s_], acc[0]);
+            acc[1] = mfma_pk16<DT>(ak, bq[1][s_], acc[1]);
+        }
+        const bool ragged = t * 32 + 32 > L;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int row = r0 + rt * 32 + j;
+            const bool window_tile = (r0 + rt * 32 + 32 > L - W) && (t * 32 + 32 > L - W);   // wave-uniform
+            float x[16];
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2 v = logit2<DT, D>(f32x2{acc[rt][e], acc[rt][e + 1]}, sqrt_d);
+                x[e] = v.x; x[e + 1] = v.y;
+            }
+            if (ragged || window_tile) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = t * 32 + 8 * (e >> 2) + 4 * kh + (e & 3);
+                    const bool masked = row >= L - W && key >= L - W && (key - (L - W)) > (row - (L - W));   // :545-551
+                    x[e] = (key >= L || masked) ? kNeg : x[e];
+                }
+            }
+            float mt = x[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mt = x[e] > mt ? x[e] : mt;
+            const float mn = mt > mrun[rt] ? mt : mrun[rt];
+            const float f = __builtin_amdgcn_exp2f((mrun[rt] - mn) * kLog2e);
+            const float c = -mn * kLog2e;
+            f32x2 part = {0.0f, 0.0f};
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2 arg = __builtin_elementwise_fma(f32x2{x[e], x[e + 1]}, (f32x2)kLog2e, (f32x2)c);
+                part = part + f32x2{__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+            }
+            srun[rt] = __builtin_fmaf(srun[rt], f, part.x + part.y);
+            mrun[rt] = mn;
+        }
+        if (t + 1 < n_t) lstore(smem + ((t + 1) & 1) * (32 * ROWP));
+        __syncthreads();
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {                                      // the two lanes of a row hold disjoint keys
+        const float mo = xor_lane<32>(mrun[rt]), so = xor_lane<32>(srun[rt]);
+        const float M = mo > mrun[rt] ? mo : mrun[rt];
+        const float S = srun[rt] * __builtin_amdgcn_exp2f((mrun[rt] - M) * kLog2e) + so * __builtin_amdgcn_exp2f((mo - M) * kLog2e);
+        const int row = r0 + rt * 32 + j;
+        if (kh == 0 && row < L) {
+            a.rowmax[(int64_t)fm.hb * L + row] = -M * kLog2e;
+            a.rinv[(int64_t)fm.hb * L + row] = 1.0f / S;
+        }
+    }
+}
+
+template <int DT, int D>
+__global__ __launch_bounds__(FAST_THREADS, 2) void h2o_fast_colsum_kernel(const H2OArgs a) {
+    typedef typename Dt<DT>::raw raw;
+    constexpr int ROWB = D * 2, ROWP = ROWB + 16, NS = D / 16, CPR = ROWB / 16, CHT = 32 * CPR / FAST_THREADS;
+    constexpr int BUF = 32 * ROWP + 256;                                  // Q tile + 32 x (mneg, rinv)
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 x BUF
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = a.q_len, W = a.window, n = L - W, n_t = (L + 31) / 32;
+    const FastMap fm = fast_map(a, blockIdx.x, (n + 255) / 256, false);
+    const int k0 = fm.blk * 256 + wave * 64;
+    const char* const qbase = reinterpret_cast<const char*>(a.q) + ((int64_t)fm.b * a.q_stride_b + (int64_t)fm.h * a.q_stride_h) * 2;
+    const int64_t qrow_bytes = a.q_stride_l * 2;
+    const float* const mneg = a.rowmax + (int64_t)fm.hb * L;
+    const float* const rinv = a.rinv + (int64_t)fm.hb * L;
+    uint4 bk[2][NS];                                                      // B operand: this lane's key row, chunk 2 s + kh
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = k0 + kt * 32 + j;
+        const char* krow = reinterpret_cast<const char*>(a.k) +
+            ((int64_t)fm.b * a.k_stride_b + (int64_t)fm.g * a.k_stride_h + (int64_t)(key < L ? key : 0) * a.k_stride_l) * 2;
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_)
+            bk[kt][s_] = key < L ? *reinterpret_cast<const uint4*>(krow + (2 * s_ + kh) * 16) : make_uint4(0, 0, 0, 0);
+    }
+    const bool live[2] = {k0 < n, k0 + 32 < n};                          // wave-uniform: a tile of columns that are all >= n is skipped
+    uint4 st[CHT];
+    float2 sst = make_float2(0.0f, 0.0f);
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < CHT; ++i) {
+            const int c = tid + FAST_THREADS * i, r = c / CPR, cc = c % CPR, row = t * 32 + r;
+            st[i] = row < L ? *reinterpret_cast<const uint4*>(qbase + (int64_t)row * qrow_bytes + cc * 16) : make_uint4(0, 0, 0, 0);
+        }
+        if (tid < 32) { const int row = t * 32 + tid; sst = row < L ? make_float2(mneg[row], rinv[row]) : make_float2(0.0f, 0.0f); }
+    };
+    auto lstore = [&](char* buf) {
+#pragma unroll
+        for (int i = 0; i < CHT; ++i) {
+            const int c = tid + FAST_THREADS * i, r = c / CPR, cc = c % CPR;
+            *reinterpret_cast<uint4*>(buf + r * ROWP + cc * 16) = st[i];
+        }
+        if (tid < 32) { reinterpret_cast<float*>(buf + 32 * ROWP)[tid] = sst.x; reinterpret_cast<float*>(buf + 32 * ROWP + 128)[tid] = sst.y; }
+    };
+    f32x2 col[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
+    const float sqrt_d = a.sqrt_d;
+    gload(0);
+    lstore(smem);
+    __syncthreads();
+    for (int t = 0; t < n_t; ++t) {
+        if (t + 1 < n_t) gload(t + 1);
+        const char* const buf = smem + (t & 1) * BUF;
+        f32x16 acc[2];
+        acc[0] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc[1] = acc[0];
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const uint4 aq = *reinterpret_cast<const uint4*>(buf + j * ROWP + (2 * s_ + kh) * 16);   // A operand: query row j of the tile
+            if (live[0]) acc[0] = mfma_pk16<DT>(aq, bk[0][s_], acc[0]);
+            if (live[1]) acc[1] = mfma_pk16<DT>(aq, bk[1][s_], acc[1]);
+        }
+        // this lane's sixteen rows of the tile: 8 g + 4 kh + e
+        float mr[16], rr[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 m4 = *reinterpret_cast<const float4*>(buf + 32 * ROWP + (8 * g4 + 4 * kh) * 4);
+            const float4 r4 = *reinterpret_cast<const float4*>(buf + 32 * ROWP + 128 + (8 * g4 + 4 * kh) * 4);
+            mr[4 * g4] = m4.x; mr[4 * g4 + 1] = m4.y; mr[4 * g4 + 2] = m4.z; mr[4 * g4 + 3] = m4.w;
+            rr[4 * g4] = r4.x; rr[4 * g4 + 1] = r4.y; rr[4 * g4 + 2] = r4.z; rr[4 * g4 + 3] = r4.w;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            if (!live[kt]) continue;
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2 x = logit2<DT, D>(f32x2{acc[kt][e], acc[kt][e + 1]}, sqrt_d);
+                const f32x2 arg = __builtin_elementwise_fma(x, (f32x2)kLog2e, f32x2{mr[e], mr[e + 1]});
+                const f32x2 pr = f32x2{__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)} * f32x2{rr[e], rr[e + 1]};
+                col[kt] = col[kt] + round2<DT>(pr);
+            }
+        }
+        if (t + 1 < n_t) lstore(smem + ((t + 1) & 1) * BUF);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        float c = col[kt].x + col[kt].y;
+        c = c + xor_lane<32>(c);                                          // the two lanes of a key hold disjoint rows
+        const int key = k0 + kt * 32 + j;
+        if (kh == 0 && key < n) reinterpret_cast<raw*>(a.scores)[(int64_t)fm.hb * n + key] = Dt<DT>::st(c);
+    }
+}
+
+// Query rows per chunk of the exact mode's logit matrix S (multiple of 256: the column sums combine 256-row blocks): as
+// many as fit in kH2OSBudget bytes, at least 512 — [Hq][rows][L] instead of [Hq][L][L] (4.1 GB at 32 heads x 8k, 65 GB at 32k).
+constexpr size_t kH2OSBudget = (size_t)1 << 30;
+int h2o_chunk_rows(int heads, int L, int esize) {
+    const size_t per256 = (size_t)heads * 256 * (size_t)L * esize;
+    size_t rows = 256 * (kH2OSBudget / (per256 ? per256 : 1));
+    if (rows < 512) rows = 512;
+    return rows >= (size_t)L ? L : (int)rows;
+}
+
+template <int DT, int D>
+static int launch_h2o_t(const H2OArgs& a0, hipStream_t st) {
     constexpr int ES = Dt<DT>::esize;
+    H2OArgs a = a0;
+    const int L = a.q_len, n = L - a.window, heads = a.bsz * a.n_q_heads;
+    if constexpr (DT != KVC_FP32) {
+        if (a.fast) {
+            const size_t lds1 = (size_t)2 * 32 * (D * 2 + 16), lds2 = (size_t)2 * (32 * (D * 2 + 16) + 256);
+            const unsigned g1 = (unsigned)(((L + 255) / 256) * heads), g2 = (unsigned)(((n + 255) / 256) * heads);
+            hipLaunchKernelGGL((h2o_fast_stats_kernel<DT, D>), dim3(g1), dim3(FAST_THREADS), lds1, st, a);
+            hipLaunchKernelGGL((h2o_fast_colsum_kernel<DT, D>), dim3(g2), dim3(FAST_THREADS), lds2, st, a);
+            return 0;
+        }
+    }
     const size_t lds = (size_t)4 * 2 * 32 * (D * ES + (DT == KVC_BF16 ? 4 : 0));   // 4 waves x 2 tile buffers (ROWP pitch)
     static LdsCache lds_cache = {};
     if (ensure_lds(reinterpret_cast<const void*>(&h2o_logits_kernel<DT, D>), lds, lds_cache) != 0) return KVC_ERR_HIP;
-    const int L = a.q_len, n = L - a.window, heads = a.bsz * a.n_q_heads;
-    const int row_tiles = (L + 31) / 32;
-    hipLaunchKernelGGL((h2o_logits_kernel<DT, D>), dim3((unsigned)((row_tiles + 3) / 4), (unsigned)heads), dim3(256), lds, st, a);
+    const bool chunked = a.s_rows < L;
     bool wide = false;
     if constexpr (DT != KVC_FP32) wide = (L % 8) == 0 && (a.window % 2) == 0 && L >= 16;
-    if constexpr (DT != KVC_FP32) {
-        if (wide) {
-            hipLaunchKernelGGL((h2o_rowsum_wide_kernel<DT>), dim3((unsigned)((L + 127) / 128), (unsigned)heads), dim3(256), 0, st, a);
-            if (L >= 512 && a.part) {
-                const unsigned n_blk = (unsigned)((L + 255) / 256);
-                hipLaunchKernelGGL((h2o_colpart_kernel<DT>), dim3((unsigned)((n / 2 + 255) / 256), (unsigned)heads, n_blk), dim3(256), 0, st, a);
-                hipLaunchKernelGGL((h2o_colcomb_kernel<DT>), dim3((unsigned)((n / 2 + 255) / 256), (unsigned)heads), dim3(256), 0, st, a);
-            } else {
-                hipLaunchKernelGGL((h2o_colsum_wide_kernel<DT>), dim3((unsigned)((n / 2 + 255) / 256), (unsigned)heads), dim3(256), 0, st, a);
+    const bool parts = a.part != nullptr && (chunked || (wide && L >= 512));    // 256-row blocks combined afterwards
+    if (chunked && !a.part) return KVC_ERR_WORKSPACE;
+    for (int row0 = 0; row0 < L; row0 += a.s_rows) {
+        a.row0 = row0;
+        a.rows = L - row0 < a.s_rows ? L - row0 : a.s_rows;
+        const int row_tiles = (a.rows + 31) / 32;
+        hipLaunchKernelGGL((h2o_logits_kernel<DT, D>), dim3((unsigned)((row_tiles + 3) / 4), (unsigned)heads), dim3(256), lds, st, a);
+        const unsigned n_blk_c = (unsigned)((a.rows + 255) / 256);
+        if constexpr (DT != KVC_FP32) {
+            if (wide) {
+                hipLaunchKernelGGL((h2o_rowsum_wide_kernel<DT>), dim3((unsigned)((a.rows + 127) / 128), (unsigned)heads), dim3(256), 0, st, a);
+                if (parts) hipLaunchKernelGGL((h2o_colpart_kernel<DT>), dim3((unsigned)((n / 2 + 255) / 256), (unsigned)heads, n_blk_c), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((h2o_colsum_wide_kernel<DT>), dim3((unsigned)((n / 2 + 255) / 256), (unsigned)heads), dim3(256), 0, st, a);
             }
         }
+        if (!wide) {
+            hipLaunchKernelGGL((h2o_rowsum_kernel<DT>), dim3((unsigned)((a.rows + 15) / 16), (unsigned)heads), dim3(256), 0, st, a);
+            if (parts) hipLaunchKernelGGL((h2o_colpart1_kernel<DT>), dim3((unsigned)((n + 255) / 256), (unsigned)heads, n_blk_c), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((h2o_colsum_kernel<DT>), dim3((unsigned)((n + 255) / 256), (unsigned)heads), dim3(256), 0, st, a);
+        }
     }
-    if (!wide) {
-        hipLaunchKernelGGL((h2o_rowsum_kernel<DT>), dim3((unsigned)((L + 15) / 16), (unsigned)heads), dim3(256), 0, st, a);
-        hipLaunchKernelGGL((h2o_colsum_kernel<DT>), dim3((unsigned)((n + 255) / 256), (unsigned)heads), dim3(256), 0, st, a);
+    if (parts) {
+        if (wide) {
+            if constexpr (DT != KVC_FP32)
+                hipLaunchKernelGGL((h2o_colcomb_kernel<DT>), dim3((unsigned)((n / 2 + 255) / 256), (unsigned)heads), dim3(256), 0, st, a);
+        } else {
+            hipLaunchKernelGGL((h2o_colcomb1_kernel<DT>), dim3((unsigned)((n + 255) / 256), (unsigned)heads), dim3(256), 0, st, a);
+        }
     }
     return 0;
 }

@@ -11,6 +11,7 @@ namespace kvc {
 constexpr int KVC_MAX_ITEMS = 32;
 struct PtrTable { const void* p[KVC_MAX_ITEMS]; };
 struct IntTable { int v[KVC_MAX_ITEMS]; };
+struct I64Table { int64_t v[KVC_MAX_ITEMS]; };
 
 struct ScoreView {         // one item's pointers, resolved at kernel entry
     const void* q; const void* k;
@@ -39,8 +40,10 @@ struct ScoreArgs {
 
 struct H2OArgs {
     const void* q; const void* k;
-    void* S;               // [bsz*Hq][L][L] dtype logits
-    float* rowmax;         // [bsz*Hq][L]
+    void* S;               // [bsz*Hq][s_rows][L] dtype logits of the query rows [row0, row0 + rows) (exact mode)
+    int row0, rows, s_rows;    // the chunk of query rows in flight and the row capacity of S per head (launcher-set)
+    int fast;              // 1: dot_mode mfma16 — two recomputing passes on the bf16/fp16 MFMA, no S at all
+    float* rowmax;         // [bsz*Hq][L]   (fast mode: -max * log2(e))
     float* rinv;           // [bsz*Hq][L]
     float* part;           // [bsz*Hq][n_blk + 1][n_pad] column sums of each 256-row block (+ the leftover rows), or null
     void* scores;          // [bsz*Hq][L-W] dtype
@@ -54,7 +57,7 @@ struct GatherArgs {
     PtrTable src, out, idx;                           // per item; idx entry may be null (identity)
     IntTable k;                                       // per item
     int64_t stride_b, stride_h, stride_l;             // elements
-    int64_t out_head_bytes;                           // bytes between heads of `out`; 0 = dense ((k + window) rows)
+    I64Table out_head_bytes;                          // per item: bytes between heads of `out`; 0 = dense ((k + window) rows)
     int bsz, n_q_heads, group, q_len, window, k_max, row_bytes, esize, n_items;
 };
 
@@ -87,6 +90,7 @@ inline int ensure_lds(const void* func, size_t lds, LdsCache& cache) {
 
 int launch_scores(const ScoreArgs& a, int dtype, int head_dim, hipStream_t st);
 int launch_h2o_scores(const H2OArgs& a, int dtype, int head_dim, hipStream_t st);
+int h2o_chunk_rows(int heads, int L, int esize);   // query rows of the exact mode's logit matrix held at a time
 int launch_select(const SelectArgs& a, int dtype, int tie_mode, hipStream_t st);
 size_t select_lds_bytes(int k);
 int launch_select_exact(const SelectArgs& a, int dtype, void* scratch, hipStream_t st);   // tie_mode torch_cpu

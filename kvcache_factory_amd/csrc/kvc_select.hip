@@ -257,7 +257,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectArgs a)
         const int per_tensor = cap * lanes_per_row;           // 16-byte pieces per tensor
         const int b = head / a.gk.n_q_heads, h = head % a.gk.n_q_heads;
         const int64_t esz = a.gk.esize, row_bytes = a.gk.row_bytes;
-        const int64_t head_bytes = a.gk.out_head_bytes ? a.gk.out_head_bytes : (int64_t)cap * row_bytes;
+        const int64_t ohb = a.gk.out_head_bytes.v[item];
+        const int64_t head_bytes = ohb ? ohb : (int64_t)cap * row_bytes;
         const int64_t tail0 = (int64_t)(a.gk.q_len - a.gk.window) - k;
         const int hk = h / a.gk.group;
         gather_head_rows<SEL_THREADS>(list, k, tail0, per_tensor, lanes_per_row, esz,

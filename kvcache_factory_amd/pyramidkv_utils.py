@@ -11,12 +11,14 @@ by one call into the HIP library (include/kvc.h: kvc_compress).  Differences, al
     opt-in: set `kvcache_factory_amd.pyramidkv_utils.VERBOSE = True` (or KVC_VERBOSE=1).
   * `merge` (LOOK-M pivot merge, :119-170) is out of scope: anything but None raises.
   * tensors must live on the GPU: there is no CPU / eager fallback.
-  * `PrefillBatch` (not in the reference): the patched forwards hand every layer's (K, window-Q, V) to it and the
-    last layer flushes them through ONE kvc_compress_batch call.  Legal because the prefill attention of each layer
-    runs on the uncompressed K/V (llama_model.py:306-313) and nothing reads the compressed cache before the first
-    decode step; the bytes are those of per-layer update_kv calls.  `BATCH_LAYERS = False` (KVC_BATCH_LAYERS=0)
-    restores one update_kv per layer.
+  * `PrefillBatch` (not in the reference): the patched forwards hand every layer's (K, window-Q, V) to it and every
+    GROUP_LAYERS-th layer (and the last) flushes the parked ones through ONE kvc_compress_batch call on a side stream,
+    beside the model's prefill of the following layers.  Legal because the prefill attention of each layer runs on the
+    uncompressed K/V (llama_model.py:306-313) and nothing reads the compressed cache before the first decode step;
+    the bytes are those of per-layer update_kv calls.  `BATCH_LAYERS = False` (KVC_BATCH_LAYERS=0) restores one
+    update_kv per layer.
 """
+import contextlib
 import math  # noqa: F401  (kept for parity with the reference's namespace)
 import os
 
@@ -26,7 +28,9 @@ from . import _kvc
 
 VERBOSE = os.environ.get("KVC_VERBOSE", "0") == "1"
 TIE_MODE = os.environ.get("KVC_TIE_MODE", "torch_cpu")   # "torch_cpu" (reference-exact ties) | "canonical"
-BATCH_LAYERS = os.environ.get("KVC_BATCH_LAYERS", "1") == "1"   # patched forwards compress all layers in one call
+BATCH_LAYERS = os.environ.get("KVC_BATCH_LAYERS", "1") == "1"   # patched forwards compress the layers in batched calls
+GROUP_LAYERS = int(os.environ.get("KVC_GROUP_LAYERS", "8"))      # ... of this many layers each (0: the whole prompt at once)
+OVERLAP = os.environ.get("KVC_OVERLAP", "1") == "1"              # grouped flushes run on a side stream beside the model's prefill
 SPARE_ROWS = 256                                         # decode rows per head reserved behind the compressed prompt
 
 
@@ -90,14 +94,22 @@ class _KVCluster:
 
 
 class PrefillBatch:
-    """The update_kv calls of one prompt, collected layer by layer and run as one batched library call.
+    """The update_kv calls of one prompt, collected layer by layer and run as batched library calls.
 
     `add` does what update_kv does up to the compute (shape assert :309, budget, pass-through test :314, pooling /
     merge errors :333/:164) and keeps K, V and a copy of the W scoring query rows; `flush` groups entries of one
-    layout, calls kvc_compress_batch per group and hands (key_states', value_states') to each entry's sink."""
+    layout, calls kvc_compress_batch per group and hands (key_states', value_states') to each entry's sink.
+
+    Bounded and overlapped: once GROUP_LAYERS entries are parked the caller flushes them (`flush(overlap=True)`).  On
+    the GPU that launch goes to a side stream which waits for the producing stream first, so the compression of
+    layers 0..7 runs while the model computes layers 8..15 — the latency-bound exact top-k (~200 us per launch whatever
+    the head count) disappears behind the model's own prefill, and at most GROUP_LAYERS layers of uncompressed K/V
+    are alive at a time instead of the whole prompt's.  `settle()` makes the current stream wait for what the side
+    stream produced; the patched forward calls it before anything reads the compressed cache."""
 
     def __init__(self):
         self.entries = []
+        self._events = []               # (event recorded on the side stream, tensors the current stream will read)
 
     def __len__(self):
         return len(self.entries)
@@ -127,24 +139,56 @@ class PrefillBatch:
         self.entries.append((tag, layout, k, qw, v, n_keep, sink, alloc))
         return True
 
-    def flush(self):
+    def flush(self, overlap=False):
         entries, self.entries = self.entries, []
         groups = {}
         for e in entries:
             groups.setdefault(e[1], []).append(e)
         for layout, es in groups.items():
-            method, _, _, _, _, _, num_heads, W, kernel_size, pooling = layout
+            method, _, _, _, _, dev, num_heads, W, kernel_size, pooling = layout
             scoring = method != _kvc.STREAMINGLLM
-            outs = None
-            if all(e[7] is not None for e in es):             # one capacity for the group: one head stride per launch
-                k0 = es[0][2]
-                cap_rows = max(e[5] for e in es) + W + SPARE_ROWS
-                outs = [e[7](k0.shape[0], num_heads, cap_rows, k0.shape[3], k0.dtype, k0.device) for e in es]
-            kc, vc = _kvc.compress_batch(method, [e[3] for e in es] if scoring else None, [e[2] for e in es],
-                                         [e[4] for e in es], W, [e[5] for e in es], kernel_size, pooling, TIE_MODE,
-                                         q_rows="window" if scoring else "all", n_q_heads=num_heads, outs=outs)
+            side = _side_stream(dev) if (overlap and OVERLAP and dev.type == "cuda") else None
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(dev))        # K, V and the query rows are complete
+                ctx = torch.cuda.stream(side)
+            else:
+                ctx = contextlib.nullcontext()
+            with ctx:
+                outs = None
+                if all(e[7] is not None for e in es):       # every layer's cache sized for its OWN budget (per-item strides)
+                    k0 = es[0][2]
+                    outs = [e[7](k0.shape[0], num_heads, e[5] + W + SPARE_ROWS, k0.shape[3], k0.dtype, k0.device) for e in es]
+                kc, vc = _kvc.compress_batch(method, [e[3] for e in es] if scoring else None, [e[2] for e in es],
+                                             [e[4] for e in es], W, [e[5] for e in es], kernel_size, pooling, TIE_MODE,
+                                             q_rows="window" if scoring else "all", n_q_heads=num_heads, outs=outs)
+            if side is not None:
+                for e in es:                                # inputs were allocated on the producing stream: keep their
+                    for t in (e[2], e[3], e[4]):            # memory until the side stream is done with them
+                        if t is not None:
+                            t.record_stream(side)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                self._events.append((ev, dev, [t for o in (outs or zip(kc, vc)) for t in o]))
             for e, a, b in zip(es, kc, vc):
                 e[6](a, b)
+
+    def settle(self):
+        """The current stream waits for every overlapped flush (no host synchronisation)."""
+        for ev, dev, outs in self._events:
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(ev)
+            for t in outs:
+                t.record_stream(cur)
+        self._events = []
+
+
+_SIDE = {}
+
+
+def _side_stream(dev):
+    if dev not in _SIDE:
+        _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return _SIDE[dev]
 
 
 class SnapKVCluster(_KVCluster):

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(kvc):
     lib = ctypes.CDLL(kvc.LIB_PATH)
     for s in syms:
         assert getattr(lib, s) is not None
-    assert kvc.lib().kvc_version() == 2
+    assert kvc.lib().kvc_version() == 3
 
 
 def test_params_struct_matches_header(kvc):
@@ -111,6 +111,24 @@ def test_null_and_misaligned_pointers_are_rejected(kvc):
 def test_pyramid_k_matches_reference(kvc, name):
     m = G.MANIFEST[name]
     assert kvc.pyramid_k(m["cap"], m["W"], m["L"], m["layer_idx"], m["n_layers"]) == (-1 if m["passthrough"] else m["n_keep"])
+
+
+def test_h2o_workspace_is_bounded(kvc):
+    """Workspace of one H2O call at Llama-3-8B shapes: exact mode <= 1 GiB of logits (+ column partials) instead of the whole
+    [32][L][L] matrix (4.1 GB at 8k, 65 GB at 32k); fast mode: two floats per query row and the scores."""
+    import ctypes
+    for L in (8000, 32000):
+        p = kvc.Params()
+        for kk, vv in dict(method=kvc.H2O, dtype=kvc.BF16, bsz=1, n_q_heads=32, n_kv_heads=8, q_len=L, head_dim=128, window=8, k=120,
+                           kernel_size=7, pooling=kvc.POOL_NONE, tie_mode=kvc.TIES_TORCH_CPU, q_stride_b=L * 4096, q_stride_h=128,
+                           q_stride_l=4096, k_stride_b=8 * L * 128, k_stride_h=L * 128, k_stride_l=128, v_stride_b=8 * L * 128,
+                           v_stride_h=L * 128, v_stride_l=128).items():
+            setattr(p, kk, vv)
+        exact = kvc.lib().kvc_workspace_bytes(ctypes.byref(p))
+        p.dot_mode = kvc.DOT_MFMA16
+        fast = kvc.lib().kvc_workspace_bytes(ctypes.byref(p))
+        assert 0 < exact <= (1 << 30) + 32 * (L // 256 + 2) * L * 4 + (1 << 22), exact
+        assert 0 < fast <= 32 * L * 8 + 32 * L * 2 + 32 * 120 * 8 + (1 << 16), fast
 
 
 def test_product_refuses_cpu_tensors(kvc):

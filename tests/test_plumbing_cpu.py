@@ -232,7 +232,8 @@ def test_layer_batching_gives_the_per_layer_cache(cpu_backend, monkeypatch, meth
     if method != "h2o":            # N1: the batched launch wrote K' / V' straight into the cache layers' own buffers
         ptrs = batch_calls[0][4]
         assert ptrs is not None and ptrs == [la._kbuf.data_ptr() for la in outs[True].past_key_values.layers]
-        assert all(la._kbuf.shape[2] == max(batch_calls[0][1]) + W + pu.SPARE_ROWS for la in outs[True].past_key_values.layers)
+        # ... each sized for its OWN budget (PyramidKV's layers differ), not for the largest of the prompt
+        assert [la._kbuf.shape[2] for la in outs[True].past_key_values.layers] == [kk + W + pu.SPARE_ROWS for kk in batch_calls[0][1]]
 
 
 def test_layer_batching_settles_an_unfinished_prefill(cpu_backend, monkeypatch):
@@ -309,3 +310,93 @@ def test_prefill_batch_groups_by_layout(cpu_backend, monkeypatch):
     assert len(pb) == 0 and sorted(c[0] for c in calls) == [1, 2]               # L = 64 twice in one call, L = 96 alone
     for name in "abc":
         assert torch.equal(got[name][0], got[name + "_want"][0]) and torch.equal(got[name][1], got[name + "_want"][1])
+
+
+@pytest.mark.parametrize("group", [0, 1, 2])
+def test_layer_batching_flushes_in_groups(cpu_backend, monkeypatch, group):
+    """pyramidkv_utils.GROUP_LAYERS bounds what stays parked: every group-th layer (and the last) flushes — 5 layers with
+    group 2 give calls of 2, 2 and 1 layers — and the cache is the per-layer one either way."""
+    model = _llama(5)
+    L, cap, W = 120, 40, 8
+    ids = torch.randint(0, 512, (1, L), generator=torch.Generator().manual_seed(7))
+    sizes = []
+
+    def spy_batch(method_, qs, ks, vs, window, keeps, *a, **kw):
+        sizes.append(len(ks))
+        return oracle_compress_batch(method_, qs, ks, vs, window, keeps, *a, **kw)
+    monkeypatch.setattr(_kvc, "compress_batch", spy_batch)
+    monkeypatch.setattr(pu, "GROUP_LAYERS", group)
+    outs = {}
+    try:
+        mp.replace_llama("pyramidkv")
+        _set_knobs(model, window_size=W, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool")
+        for flag in (False, True):
+            monkeypatch.setattr(pu, "BATCH_LAYERS", flag)
+            outs[flag] = _generate(model, ids, 2)
+    finally:
+        mp.replace_llama("fullkv")
+    assert sizes == {0: [5], 1: [1] * 5, 2: [2, 2, 1]}[group]
+    assert torch.equal(outs[True].sequences, outs[False].sequences)
+    for la, lb in zip(outs[True].past_key_values.layers, outs[False].past_key_values.layers):
+        assert torch.equal(la.keys, lb.keys) and torch.equal(la.values, lb.values)
+
+
+@pytest.mark.parametrize("impl", ["eager", "sdpa"])
+@pytest.mark.parametrize("method", ["pyramidkv", "snapkv"])
+def test_generate_with_eager_and_sdpa_attention(cpu_backend, monkeypatch, method, impl):
+    """Decode over layers that store DIFFERENT numbers of tokens (PyramidKV): transformers builds one mask per forward from
+    the first layer's lengths and its eager attention adds it uncut — the patched forward trims it to each layer's keys.
+    Eager and sdpa generate the same tokens; batched and per-layer compression too."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=256, num_hidden_layers=4, num_attention_heads=8,
+                      num_key_value_heads=2, head_dim=64, vocab_size=512, max_position_embeddings=4096,
+                      attn_implementation=impl)
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(cfg).eval()
+    L, cap, W = 200, 40, 8
+    ids = torch.randint(0, 512, (1, L), generator=torch.Generator().manual_seed(8))
+    outs = {}
+    try:
+        mp.replace_llama(method)
+        _set_knobs(model, window_size=W, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool")
+        for flag in (False, True):
+            monkeypatch.setattr(pu, "BATCH_LAYERS", flag)
+            outs[flag] = _generate(model, ids, 4)
+    finally:
+        mp.replace_llama("fullkv")
+    assert torch.equal(outs[True].sequences, outs[False].sequences) and outs[True].sequences.shape[1] == L + 4
+    stored = [la.keys.shape[2] for la in outs[True].past_key_values.layers]
+    if method == "pyramidkv":
+        assert len(set(stored)) > 1                                     # the layers really differ
+    test_generate_with_eager_and_sdpa_attention.tokens = getattr(test_generate_with_eager_and_sdpa_attention, "tokens", {})
+    test_generate_with_eager_and_sdpa_attention.tokens[(method, impl)] = outs[True].sequences
+    other = test_generate_with_eager_and_sdpa_attention.tokens.get((method, "eager" if impl == "sdpa" else "sdpa"))
+    if other is not None:
+        assert torch.equal(other, outs[True].sequences)
+
+
+def test_decode_mask_is_trimmed_per_layer(cpu_backend):
+    """A materialised 4-D mask wider than a layer's stored keys (built from another layer's length) is cut to its last
+    columns in the decode branch; one that is too narrow is an error, not a silent broadcast."""
+    from transformers import DynamicCache
+    model = _llama(2)
+    attn = model.model.layers[1].self_attn
+    try:
+        mp.replace_llama("snapkv")
+        _set_knobs(model, window_size=8, max_capacity_prompt=48, kernel_size=7, pooling="maxpool")
+        cache = DynamicCache()
+        hs = torch.randn(1, 100, 4096, generator=torch.Generator().manual_seed(4))
+        pos = model.model.rotary_emb(hs, torch.arange(100)[None])
+        with torch.no_grad():
+            attn(hs, position_embeddings=pos, attention_mask=None, past_key_values=cache)
+            pos1 = model.model.rotary_emb(hs[:, :1], torch.tensor([[100]]))
+            ref, _ = attn(hs[:, :1], position_embeddings=pos1, attention_mask=None, past_key_values=cache)
+            cache.layers[1]._stored -= 1; cache.layers[1].true_length -= 1          # undo the append, decode again
+            wide = torch.zeros(1, 1, 1, 80)                                          # 80 > 49 stored keys
+            out, _ = attn(hs[:, :1], position_embeddings=pos1, attention_mask=wide, past_key_values=cache)
+            assert torch.allclose(out, ref, atol=1e-5)
+            cache.layers[1]._stored -= 1; cache.layers[1].true_length -= 1
+            with pytest.raises(RuntimeError, match="attention mask covers"):
+                attn(hs[:, :1], position_embeddings=pos1, attention_mask=torch.zeros(1, 1, 1, 20), past_key_values=cache)
+    finally:
+        mp.replace_llama("fullkv")

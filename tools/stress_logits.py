@@ -16,8 +16,7 @@ bad_total = 0
 for rep in range(reps):
     for t in sc:
         t.zero_()
-    rc = kvc.lib().kvc_compress_batch(ctypes.byref(bp.p), bp.n, bp._keep, bp._q, bp._k, bp._v, bp._ko, bp._vo, bp._ix, arr,
-                                      kvc._ptr(bp.ws), bp.nbytes, kvc._stream(dev))
+    rc = bp.call(scores_out=arr)
     assert rc == 0, kvc.lib().kvc_last_error()
     torch.cuda.synchronize()
     bad = sum(int((a.view(torch.int16) != b.view(torch.int16)).sum()) for a, b in zip(sc, ref))
