@@ -169,6 +169,33 @@ int kvc_gather(const kvc_params* p, const void* src, int64_t stride_b, int64_t s
 int64_t kvc_pyramid_k(int64_t max_capacity_prompt, int64_t window, int64_t q_len,
                       int64_t layer_idx, int64_t num_hidden_layers, int64_t beta);
 
+/* ---- decode side: one decode step over the compacted cache -------------------------------------------
+ * Replaces, per layer and step, the reference's `past_key_value.update` else-branch (llama_model.py:287-289: repeat_kv of
+ * the new K/V to H_q heads + torch.cat onto the [1, H_q, cap + t, D] cache) and the SDPA over the result (:306-313).
+ * The cache is kept in two parts: the PREFIX [b][H_q][prefix_rows][D] is what kvc_compress wrote (k + W rows per query
+ * head; it may live in a buffer with a larger head stride) and is never touched again; the TAIL [b][H_kv][capacity][D]
+ * holds the decoded tokens ONCE per KV head.  The call appends the step's `new_rows` K/V rows to the tail in place
+ * (rows tail_rows ..) and writes, for every query head and new token i, softmax(q K^T * scaling) V over the head's prefix
+ * rows and its KV head's tail rows [0, tail_rows + i + 1) — fp32 accumulation, output in dtype.  All strides in elements;
+ * rows are dense (head_dim elements); head_dim 64 or 128; capacity >= tail_rows + new_rows is the caller's business. */
+typedef struct kvc_decode_params {
+    int32_t dtype;             /* kvc_dtype of every tensor */
+    int32_t bsz, n_q_heads, n_kv_heads, head_dim;
+    int32_t prefix_rows;       /* rows per query head in the prefix (k + W) */
+    int32_t tail_rows;         /* rows already in the tail before this call */
+    int32_t new_rows;          /* tokens of this step (rows of q, k_new, v_new) */
+    float scaling;             /* softmax scale, 1 / sqrt(head_dim) for Llama / Mistral */
+    int32_t reserved;
+    int64_t q_stride_b, q_stride_h, q_stride_l;             /* q[b][h_q][i][:] */
+    int64_t new_stride_b, new_stride_h, new_stride_l;       /* k_new / v_new [b][h_kv][i][:] */
+    int64_t prefix_stride_b, prefix_stride_h;               /* k_prefix / v_prefix [b][h_q][row][:] */
+    int64_t tail_stride_b, tail_stride_h;                   /* k_tail / v_tail [b][h_kv][row][:] */
+    int64_t out_stride_b, out_stride_h, out_stride_l;       /* out[b][h_q][i][:] */
+} kvc_decode_params;
+
+int kvc_decode_step(const kvc_decode_params* p, const void* q, const void* k_new, const void* v_new,
+                    const void* k_prefix, const void* v_prefix, void* k_tail, void* v_tail, void* out, void* hip_stream);
+
 /* Debug/parity aid: byte offsets inside the workspace of the intermediates kvc_scores leaves behind.
  * offs[0]=logits [b][h][L][W] dtype, offs[1]=row max [b][h][W] f32, offs[2]=row sum [b][h][W] f32.
  * Returns KVC_OK or an error. */

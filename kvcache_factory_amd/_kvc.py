@@ -23,7 +23,7 @@ DOT_MODE = os.environ.get("KVC_DOT_MODE", "exact")      # default of every helpe
 
 EXPORTS = ("kvc_version", "kvc_last_error", "kvc_workspace_bytes", "kvc_compress", "kvc_scores", "kvc_select",
            "kvc_gather", "kvc_pyramid_k", "kvc_workspace_layout", "kvc_workspace_bytes_batch", "kvc_compress_batch",
-           "kvc_select_workspace_bytes")
+           "kvc_select_workspace_bytes", "kvc_decode_step")
 
 
 class KvcError(RuntimeError):
@@ -39,6 +39,14 @@ class Params(ctypes.Structure):
         (n, ctypes.c_int64) for n in (
             "q_stride_b", "q_stride_h", "q_stride_l", "k_stride_b", "k_stride_h", "k_stride_l",
             "v_stride_b", "v_stride_h", "v_stride_l", "out_stride_h")]
+
+
+class DecodeParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("dtype", "bsz", "n_q_heads", "n_kv_heads", "head_dim", "prefix_rows", "tail_rows",
+                                               "new_rows")] + [("scaling", ctypes.c_float), ("reserved", ctypes.c_int32)] + [
+        (n, ctypes.c_int64) for n in ("q_stride_b", "q_stride_h", "q_stride_l", "new_stride_b", "new_stride_h", "new_stride_l",
+                                      "prefix_stride_b", "prefix_stride_h", "tail_stride_b", "tail_stride_h",
+                                      "out_stride_b", "out_stride_h", "out_stride_l")]
 
 
 _lib = None
@@ -68,6 +76,7 @@ def lib():
         L.kvc_workspace_bytes_batch.argtypes = [pp, ctypes.c_int, vp]
         L.kvc_workspace_bytes_batch.restype = sz
         L.kvc_compress_batch.argtypes = [pp, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+        L.kvc_decode_step.argtypes = [ctypes.POINTER(DecodeParams)] + [vp] * 9
         L.kvc_select_workspace_bytes.argtypes = [pp]
         L.kvc_select_workspace_bytes.restype = sz
         _lib = L
@@ -268,6 +277,32 @@ def gather(src, idx, window, n_q_heads):
     dev = _one_device(src, idx)
     _check(_call(dev, lib().kvc_gather, ctypes.byref(p), _ptr(src), src.stride(0), src.stride(1), src.stride(2),
                  _ptr(idx.contiguous() if idx is not None else None), _ptr(out), _stream(dev)))
+    return out
+
+
+def decode_step(q, k_new, v_new, k_prefix, v_prefix, prefix_rows, k_tail, v_tail, tail_rows, scaling):
+    """One decode step over the compacted cache (kvc_decode_step): appends k_new / v_new [b, H_kv, t, D] to the tail buffers
+    [b, H_kv, capacity, D] at row tail_rows and returns the attention output [b, t, H_q, D] of q [b, H_q, t, D] over the
+    first prefix_rows rows per query head of k_prefix / v_prefix [b, H_q, >= prefix_rows, D] and the tail."""
+    _require_gpu(q, k_new, v_new, k_prefix, v_prefix, k_tail, v_tail)
+    dev = _one_device(q, k_new, v_new, k_prefix, v_prefix, k_tail, v_tail)
+    q, k_new, v_new = _last_dim_contig(q), _last_dim_contig(k_new), _last_dim_contig(v_new)
+    b, hq, t, D = q.shape
+    assert k_tail.shape[2] >= tail_rows + t and k_new.shape == v_new.shape and k_new.shape[2] == t
+    assert k_new.stride() == v_new.stride() and k_tail.stride() == v_tail.stride() and k_prefix.stride() == v_prefix.stride()
+    for x in (k_prefix, v_prefix, k_tail, v_tail):
+        assert x.stride(3) == 1 and x.stride(2) == D, "cache rows must be dense"
+    out = torch.empty(b, t, hq, D, dtype=q.dtype, device=dev)
+    p = DecodeParams()
+    p.dtype, p.bsz, p.n_q_heads, p.n_kv_heads, p.head_dim = DTYPES[q.dtype], b, hq, k_new.shape[1], D
+    p.prefix_rows, p.tail_rows, p.new_rows, p.scaling = prefix_rows, tail_rows, t, scaling
+    p.q_stride_b, p.q_stride_h, p.q_stride_l = q.stride(0), q.stride(1), q.stride(2)
+    p.new_stride_b, p.new_stride_h, p.new_stride_l = k_new.stride(0), k_new.stride(1), k_new.stride(2)
+    p.prefix_stride_b, p.prefix_stride_h = k_prefix.stride(0), k_prefix.stride(1)
+    p.tail_stride_b, p.tail_stride_h = k_tail.stride(0), k_tail.stride(1)
+    p.out_stride_b, p.out_stride_h, p.out_stride_l = out.stride(0), out.stride(2), out.stride(1)
+    _check(_call(dev, lib().kvc_decode_step, ctypes.byref(p), _ptr(q), _ptr(k_new), _ptr(v_new), _ptr(k_prefix), _ptr(v_prefix),
+                 _ptr(k_tail), _ptr(v_tail), _ptr(out), _stream(dev)))
     return out
 
 

@@ -10,7 +10,9 @@
          parked ones as one kvc_compress_batch on a side stream while the model goes on — same bytes, one launch of each
          kernel per group instead of one per layer, off the model's critical path]
         attention of THIS step runs over the uncompressed K, V                                  (:306-313)
-    decode   : append the new token (expanded to H_q heads) and attend over cap + t tokens      (:287-289)
+    decode   : append the new token and attend over cap + t tokens                              (:287-289, :306-313)
+        [default, pyramidkv_utils.DECODE_KERNEL: one fused step — the token's K/V go ONCE per KV head to the layer's tail and
+         kvc_decode_step attends over prefix + tail; otherwise the reference's shape: repeat_kv, append, attention]
 
 Written against transformers 5.x (single *Attention class, `past_key_values` kwarg, attention dispatched through
 ALL_ATTENTION_FUNCTIONS, DynamicCache of per-layer objects); the reference targets 4.44.2 class names that no
@@ -61,6 +63,16 @@ def _layer_for(cache, layer_idx):
     return layer
 
 
+def _fusable(module, layer, hidden_states, attention_mask, kwargs):
+    """The fused decode step (kvc_decode_step) covers the reference's own use: inference, bsz = 1 (README.md:29: no batch
+    inference — a padding mask cannot be mapped onto evicted positions anyway), GPU tensors, head_dim 64 / 128, no attention
+    weights requested, no sliding window.  Anything else takes the reference-shaped path (repeat_kv + cat + attention)."""
+    return (hidden_states.is_cuda and hidden_states.shape[0] == 1 and not module.training and layer.can_split()
+            and module.head_dim in (64, 128) and not kwargs.get("output_attentions", False)
+            and getattr(module.config, "sliding_window", None) is None
+            and hidden_states.dtype in (torch.bfloat16, torch.float16, torch.float32))
+
+
 def _pending_for(cache):
     """The prompt's PrefillBatch, kept on the cache object (one per generation)."""
     pending = getattr(cache, "_kvc_pending", None)
@@ -109,6 +121,12 @@ def make_forward(method, apply_rotary_pos_emb, eager_attention_forward, repeat_k
                 # this step's attention sees the full, uncompressed K/V (H_kv heads; the interface expands)
             else:                                                            # decode over the compressed cache
                 pending.settle()
+                if pu.DECODE_KERNEL and _fusable(self, layer, hidden_states, attention_mask, kwargs):
+                    # N1: the step's K/V rows go to the layer's shared tail (once per KV head) and ONE kernel attends over
+                    # prefix + tail — no repeat_kv, no copy of the cache (reference: llama_model.py:287-289, 306-313)
+                    attn_output = layer.decode_attend(query_states, key_states, value_states, self.scaling)
+                    attn_output = attn_output.reshape(*input_shape, -1)
+                    return self.o_proj(attn_output), None
                 key_states = repeat_kv(key_states, self.num_key_value_groups)
                 value_states = repeat_kv(value_states, self.num_key_value_groups)
                 key_states, value_states = past_key_values.update(key_states, value_states, self.layer_idx)

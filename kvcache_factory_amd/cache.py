@@ -10,30 +10,64 @@ from transformers.cache_utils import DynamicLayer
 
 
 class CompressedDynamicLayer(DynamicLayer):
-    """Stores [bsz, H_q, stored, D] (H_q heads, like the reference's cache after repeat_kv) and counts real tokens.
+    """The compressed prompt of one layer plus the decoded tokens, in one of two forms.
 
-    Decode side (first step): the reference's cache grows by `torch.cat` on every generated token
-    (`past_key_value.update` else-branch, llama_model.py:287-289) — a copy of the whole [1, 32, cap + t, 128] tensor
-    per layer per step.  Here the compressed prompt is placed once into a buffer with `RESERVE` spare rows per head
-    (doubled when exhausted); a decode step writes its row(s) in place and hands out views of the filled part.  Same
-    bytes, no per-token reallocation."""
+    EXPANDED (the reference's form): `[bsz, H_q, stored, D]` — H_q heads like the reference's cache after repeat_kv.  The
+    reference grows it by `torch.cat` on every generated token (`past_key_value.update` else-branch, llama_model.py:287-289:
+    a copy of the whole [1, 32, cap + t, 128] tensor per layer per step); here the compressed prompt sits in a buffer with
+    spare rows per head (doubled when exhausted) and a decode step writes its row(s) in place.  Same bytes.
 
-    RESERVE = 256                       # spare rows per head allocated with the compressed prompt
+    SPLIT (used by the fused decode step, `decode_attend`): the prefix `[bsz, H_q, k + W, D]` stays exactly
+    where the compression kernels wrote it and the decoded tokens go to a TAIL `[bsz, H_kv, capacity, D]` — once per KV
+    head, not H_q / H_kv times, with no repeat_kv and no copy of the prefix.  `keys` / `values` materialise the reference's
+    view on demand (tests, tools); asking for them through `update` converts the layer to EXPANDED for good."""
+
+    RESERVE = 256                       # spare rows allocated with the compressed prompt / tail rows allocated at a time
 
     def __init__(self):
         super().__init__()
         self.true_length = 0            # tokens the model has really seen for this layer
         self._kbuf = self._vbuf = None  # [bsz, H_q, capacity, D]
-        self._stored = 0
+        self._stored = 0                # rows in use per head of _kbuf / _vbuf
+        self._ktail = self._vtail = None    # SPLIT form: [bsz, H_kv, capacity, D]
+        self._tail = 0
+        self._split = False
 
+    # ---- the reference's view --------------------------------------------------------------------------------------
+    # (`keys` / `values` are plain attributes of DynamicLayer; here they are computed from the buffers)
+    @property
+    def keys(self):
+        return self._view(self._kbuf, self._ktail)
+
+    @keys.setter
+    def keys(self, value):              # DynamicLayer.lazy_initialization assigns empty tensors
+        pass
+
+    @property
+    def values(self):
+        return self._view(self._vbuf, self._vtail)
+
+    @values.setter
+    def values(self, value):
+        pass
+
+    def _view(self, buf, tail):
+        if buf is None:
+            return None
+        pre = buf[:, :, :self._stored]
+        if not self._split or self._tail == 0:
+            return pre
+        g = buf.shape[1] // tail.shape[1]
+        return torch.cat([pre, tail[:, :, :self._tail].repeat_interleave(g, dim=1)], dim=2)
+
+    # ---- prefill ------------------------------------------------------------------------------------------------------
     def _place(self, k, v, spare):
         b, h, n, d = k.shape
-        self._kbuf = torch.empty(b, h, n + spare, d, dtype=k.dtype, device=k.device)
-        self._vbuf = torch.empty_like(self._kbuf)
-        self._kbuf[:, :, :n].copy_(k)
-        self._vbuf[:, :, :n].copy_(v)
-        self._stored = n
-        self.keys, self.values = self._kbuf[:, :, :n], self._vbuf[:, :, :n]
+        kb = torch.empty(b, h, n + spare, d, dtype=k.dtype, device=k.device)
+        vb = torch.empty_like(kb)
+        kb[:, :, :n].copy_(k)
+        vb[:, :, :n].copy_(v)
+        self._kbuf, self._vbuf, self._stored = kb, vb, n
 
     def reserve(self, bsz, n_heads, capacity, head_dim, dtype, device):
         """Buffers [bsz, H_q, capacity, D] the compression kernels write K' / V' into directly (kvc_params.out_stride_h):
@@ -49,30 +83,70 @@ class CompressedDynamicLayer(DynamicLayer):
         if self._kbuf is not None and k_compressed.data_ptr() == self._kbuf.data_ptr() and \
                 v_compressed.data_ptr() == self._vbuf.data_ptr():      # already written into our own buffers
             self._stored = k_compressed.shape[2]
-            self.keys, self.values = self._kbuf[:, :, :self._stored], self._vbuf[:, :, :self._stored]
         else:
             self._place(k_compressed, v_compressed, self.RESERVE)
+        self._split, self._tail, self._ktail, self._vtail = False, 0, None, None
         self.true_length = int(true_length)
 
+    # ---- decode: the reference-shaped path ----------------------------------------------------------------------------
+    def _expand(self):
+        """SPLIT -> EXPANDED (a caller wants plain H_q-head tensors to attend over)."""
+        if self._split:
+            k, v = self.keys, self.values
+            self._split, self._tail, self._ktail, self._vtail = False, 0, None, None
+            self._place(k, v, self.RESERVE)
+
     def update(self, key_states, value_states, *args, **kwargs):
+        """Append H_q-head rows (the caller repeat_kv-expanded them like the reference) and return the whole cache."""
         if not self.is_initialized:
             self.lazy_initialization(key_states, value_states)
         t = key_states.shape[-2]
+        self._expand()
         if self._kbuf is None:                                    # a layer that never went through prefill()
             self._place(key_states, value_states, self.RESERVE)
         else:
             if self._stored + t > self._kbuf.shape[2]:            # out of spare rows: double
-                self._place(self.keys, self.values, max(self._kbuf.shape[2], t))
+                self._place(self._kbuf[:, :, :self._stored], self._vbuf[:, :, :self._stored], max(self._kbuf.shape[2], t))
             n = self._stored
             self._kbuf[:, :, n:n + t].copy_(key_states)
             self._vbuf[:, :, n:n + t].copy_(value_states)
             self._stored = n + t
-            self.keys, self.values = self._kbuf[:, :, :n + t], self._vbuf[:, :, :n + t]
         self.true_length += t
         return self.keys, self.values
 
+    # ---- decode: the fused step ---------------------------------------------------------------------------------------
+    def decode_attend(self, query_states, key_states, value_states, scaling):
+        """One decode step in the SPLIT form: key_states / value_states [bsz, H_kv, t, D] are appended to the tail by the
+        kernel and the attention output [bsz, t, H_q, D] over prefix + tail comes back (kvc_decode_step)."""
+        from . import _kvc
+        t = key_states.shape[-2]
+        b, hkv, _, d = key_states.shape
+        if not self._split:
+            self._split, self._tail = True, 0
+            self._ktail = torch.empty(b, hkv, self.RESERVE, d, dtype=key_states.dtype, device=key_states.device)
+            self._vtail = torch.empty_like(self._ktail)
+        if self._tail + t > self._ktail.shape[2]:                 # tail full: double it
+            cap = max(2 * self._ktail.shape[2], self._tail + t)
+            kt = torch.empty(b, hkv, cap, d, dtype=self._ktail.dtype, device=self._ktail.device)
+            vt = torch.empty_like(kt)
+            kt[:, :, :self._tail].copy_(self._ktail[:, :, :self._tail])
+            vt[:, :, :self._tail].copy_(self._vtail[:, :, :self._tail])
+            self._ktail, self._vtail = kt, vt
+        out = _kvc.decode_step(query_states, key_states, value_states, self._kbuf, self._vbuf, self._stored,
+                               self._ktail, self._vtail, self._tail, scaling)
+        self._tail += t
+        self.true_length += t
+        return out
+
+    def can_split(self):
+        """The fused decode step needs the prefix in this layer's own buffers (a layer that went through prefill)."""
+        return self._kbuf is not None
+
+    # ---- bookkeeping --------------------------------------------------------------------------------------------------
     def stored_length(self):
-        return 0 if (not self.is_initialized or self.keys.numel() == 0) else self.keys.shape[-2]
+        if self._kbuf is None:
+            return 0
+        return self._stored + (self._tail if self._split else 0)
 
     def get_seq_length(self):
         return self.true_length

@@ -445,6 +445,39 @@ __attribute__((visibility("default"))) int kvc_gather(const kvc_params* p, const
     return enqueue_gather(&g, nullptr, static_cast<hipStream_t>(hip_stream));
 }
 
+__attribute__((visibility("default"))) int kvc_decode_step(const kvc_decode_params* p, const void* q, const void* k_new, const void* v_new,
+                                                           const void* k_prefix, const void* v_prefix, void* k_tail, void* v_tail,
+                                                           void* out, void* hip_stream) {
+    if (!p) return fail(KVC_ERR_INVALID, "params is NULL");
+    if (p->dtype < KVC_BF16 || p->dtype > KVC_FP32) return fail(KVC_ERR_INVALID, "unknown dtype %d", p->dtype);
+    if (p->bsz < 1 || p->n_q_heads < 1 || p->n_kv_heads < 1 || p->n_q_heads % p->n_kv_heads)
+        return fail(KVC_ERR_INVALID, "bsz / head counts invalid");
+    if (p->head_dim != 64 && p->head_dim != 128) return fail(KVC_ERR_UNSUPPORTED, "decode kernels are built for head_dim 64 and 128, got %d", p->head_dim);
+    if (p->prefix_rows < 0 || p->tail_rows < 0 || p->new_rows < 1) return fail(KVC_ERR_INVALID, "row counts invalid");
+    if (!q || !k_new || !v_new || !k_tail || !v_tail || !out || (p->prefix_rows > 0 && (!k_prefix || !v_prefix)))
+        return fail(KVC_ERR_INVALID, "q, k_new, v_new, the tail, out (and the prefix when it has rows) must be non-NULL");
+    const int es = esize_of(p->dtype);
+    const void* ptrs[] = {q, k_new, v_new, k_prefix, v_prefix, k_tail, v_tail};
+    for (const void* x : ptrs) if (((uintptr_t)x) % 16) return fail(KVC_ERR_ALIGNMENT, "a pointer is not 16-byte aligned");
+    const int64_t strides[] = {p->q_stride_b, p->q_stride_h, p->q_stride_l, p->new_stride_b, p->new_stride_h, p->new_stride_l,
+                               p->prefix_stride_b, p->prefix_stride_h, p->tail_stride_b, p->tail_stride_h};
+    for (int64_t sd : strides) if ((sd * es) % 16) return fail(KVC_ERR_ALIGNMENT, "a stride is not a multiple of 16 bytes");
+    kvc::DecodeArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.q = q; a.k_new = k_new; a.v_new = v_new; a.k_prefix = k_prefix; a.v_prefix = v_prefix; a.k_tail = k_tail; a.v_tail = v_tail; a.out = out;
+    a.q_stride_b = p->q_stride_b; a.q_stride_h = p->q_stride_h; a.q_stride_l = p->q_stride_l;
+    a.new_stride_b = p->new_stride_b; a.new_stride_h = p->new_stride_h; a.new_stride_l = p->new_stride_l;
+    a.prefix_stride_b = p->prefix_stride_b; a.prefix_stride_h = p->prefix_stride_h;
+    a.tail_stride_b = p->tail_stride_b; a.tail_stride_h = p->tail_stride_h;
+    a.out_stride_b = p->out_stride_b; a.out_stride_h = p->out_stride_h; a.out_stride_l = p->out_stride_l;
+    a.bsz = p->bsz; a.n_q_heads = p->n_q_heads; a.n_kv_heads = p->n_kv_heads; a.group = p->n_q_heads / p->n_kv_heads;
+    a.prefix_rows = p->prefix_rows; a.tail_rows = p->tail_rows; a.new_rows = p->new_rows;
+    a.esize = es; a.row_bytes = p->head_dim * es; a.scaling = p->scaling;
+    if (int rc = kvc::launch_decode_step(a, p->dtype, p->head_dim, static_cast<hipStream_t>(hip_stream)))
+        return fail(rc, "no decode kernel for dtype %d head_dim %d", p->dtype, p->head_dim);
+    return hip_ok("decode step launch");
+}
+
 __attribute__((visibility("default"))) int kvc_compress(const kvc_params* p, const void* q, const void* k, const void* v,
                                                         void* k_out, void* v_out, int64_t* idx_out, void* scores_out,
                                                         void* workspace, size_t workspace_bytes, void* hip_stream) {

@@ -74,6 +74,19 @@ struct SelectArgs {
 
 struct GatherPair { GatherArgs t[2]; int count; };    // K and V compacted by one launch
 
+struct DecodeArgs {        // one decode step over the compacted cache (kvc_decode.hip); strides in elements
+    const void* q; const void* k_new; const void* v_new;
+    const void* k_prefix; const void* v_prefix;       // [b][Hq][prefix rows][D]
+    void* k_tail; void* v_tail;                       // [b][Hkv][capacity][D], rows [0, tail_rows) filled
+    void* out;                                        // attention output, row (b, h, i) at out + b*sb + h*sh + i*sl
+    int64_t q_stride_b, q_stride_h, q_stride_l;
+    int64_t new_stride_b, new_stride_h, new_stride_l;
+    int64_t prefix_stride_b, prefix_stride_h, tail_stride_b, tail_stride_h;
+    int64_t out_stride_b, out_stride_h, out_stride_l;
+    int bsz, n_q_heads, n_kv_heads, group, prefix_rows, tail_rows, new_rows, esize, row_bytes;
+    float scaling;
+};
+
 // Raise a kernel's dynamic-LDS limit above 64 KB once per (kernel instantiation, device): `cache` is a function-local
 // static array owned by the caller.  Never called again on the launch path, so launches stay graph-capturable.
 struct LdsCache { size_t ok[16]; };
@@ -96,6 +109,7 @@ size_t select_lds_bytes(int k);
 int launch_select_exact(const SelectArgs& a, int dtype, void* scratch, hipStream_t st);   // tie_mode torch_cpu
 size_t select_exact_scratch_bytes(int heads, int n, int k);     // per item
 int launch_gather(const GatherPair& p, hipStream_t st);
+int launch_decode_step(const DecodeArgs& a, int dtype, int head_dim, hipStream_t st);
 static constexpr int kFuseGatherMaxK = 512;   // select_kernel gathers the rows itself up to this k
 
 }  // namespace kvc

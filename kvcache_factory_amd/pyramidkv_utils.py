@@ -30,6 +30,7 @@ VERBOSE = os.environ.get("KVC_VERBOSE", "0") == "1"
 TIE_MODE = os.environ.get("KVC_TIE_MODE", "torch_cpu")   # "torch_cpu" (reference-exact ties) | "canonical"
 BATCH_LAYERS = os.environ.get("KVC_BATCH_LAYERS", "1") == "1"   # patched forwards compress the layers in batched calls
 GROUP_LAYERS = int(os.environ.get("KVC_GROUP_LAYERS", "8"))      # ... of this many layers each (0: the whole prompt at once)
+DECODE_KERNEL = os.environ.get("KVC_DECODE_KERNEL", "1") == "1"  # decode steps by kvc_decode_step over the split cache (N1)
 OVERLAP = os.environ.get("KVC_OVERLAP", "1") == "1"              # grouped flushes run on a side stream beside the model's prefill
 SPARE_ROWS = 256                                         # decode rows per head reserved behind the compressed prompt
 

@@ -721,3 +721,75 @@ def test_patched_mistral_on_gpu(kvc, gpu_device):
     for la, lb in zip(outs[True].past_key_values.layers, outs[False].past_key_values.layers):
         assert la.get_seq_length() == lb.get_seq_length() == L + 2 and la.keys.shape[2] == cap + 2
         assert torch.equal(la.keys, lb.keys) and torch.equal(la.values, lb.values)
+
+
+@pytest.mark.parametrize("dtype,D,hq,hkv,P,T,t", [(torch.bfloat16, 128, 32, 8, 128, 0, 1), (torch.bfloat16, 128, 32, 8, 128, 37, 1),
+                                                  (torch.float16, 64, 8, 2, 40, 5, 3), (torch.float32, 128, 4, 4, 70, 9, 2),
+                                                  (torch.bfloat16, 128, 32, 8, 2056, 300, 1)])
+def test_decode_step_vs_reference_shaped_attention(kvc, gpu_device, dtype, D, hq, hkv, P, T, t):
+    """kvc_decode_step (N1): append the step's K/V to the per-KV-head tail and attend over prefix + tail == SDPA over the
+    reference-shaped cache cat(prefix, repeat_kv(tail + new)) (llama_model.py:287-289, 306-313), causal among the step's
+    tokens.  Tolerance: fp32 reference computed from the same inputs, |diff| <= 2 ulp-ish of the dtype (2^-7 bf16, 2^-10
+    fp16, 1e-5 fp32, relative to max |out|); the tail must hold the appended rows byte for byte."""
+    g = torch.Generator().manual_seed(P + T)
+    rn = lambda *sh: torch.randn(*sh, generator=g).to(dtype).to(gpu_device)      # noqa: E731
+    q, kn, vn = rn(1, hq, t, D), rn(1, hkv, t, D), rn(1, hkv, t, D)
+    kp, vp = rn(1, hq, P + 7, D), rn(1, hq, P + 7, D)                     # buffers with spare rows per head
+    kt, vt = rn(1, hkv, T + t + 4, D), rn(1, hkv, T + t + 4, D)
+    kt0, vt0 = kt.clone(), vt.clone()
+    out = kvc.decode_step(q, kn, vn, kp, vp, P, kt, vt, T, D ** -0.5)
+    assert out.shape == (1, t, hq, D)
+    assert torch.equal(kt[:, :, T:T + t], kn) and torch.equal(vt[:, :, T:T + t], vn)
+    assert torch.equal(kt[:, :, :T], kt0[:, :, :T]) and torch.equal(kt[:, :, T + t:], kt0[:, :, T + t:])
+    grp = hq // hkv
+    K = torch.cat([kp[:, :, :P], kt[:, :, :T + t].repeat_interleave(grp, 1)], 2).float()
+    V = torch.cat([vp[:, :, :P], vt[:, :, :T + t].repeat_interleave(grp, 1)], 2).float()
+    mask = torch.zeros(t, P + T + t, device=gpu_device)
+    for i in range(t):
+        mask[i, P + T + i + 1:] = float("-inf")
+    ref = torch.softmax(q.float() @ K.transpose(2, 3) * D ** -0.5 + mask, -1) @ V          # [1, hq, t, D]
+    tol = {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10, torch.float32: 1e-5}[dtype]
+    assert float((out.transpose(1, 2).float() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("method", ["snapkv", "pyramidkv"])
+def test_decode_logits_vs_oracle_built_cache(kvc, oracle, gpu_device, method, monkeypatch):
+    """N1 end to end against the ORACLE, not against the HIP path: a small bf16 Llama (32 q / 8 kv heads of 128) decodes
+    (a) on the split cache with the fused decode kernel (default) and (b) the reference's way — the cache is the CPU
+    oracle's K' / V' (reference-shaped, 32 heads), every decode step repeat_kv + cat + stock SDPA.  Same tokens; decode-step
+    logits equal within bf16 rounding of two different attention kernels (|diff| <= 3e-2 * max |logit|)."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from kvcache_factory_amd import monkeypatch as mp, pyramidkv_utils as pu
+    import cpu_compress
+    cfg = LlamaConfig(hidden_size=4096, intermediate_size=256, num_hidden_layers=3, num_attention_heads=32,
+                      num_key_value_heads=8, head_dim=128, vocab_size=256, max_position_embeddings=4096, attn_implementation="sdpa")
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(cfg).to(torch.bfloat16).to(gpu_device).eval()
+    ids = torch.randint(0, 256, (1, 500), generator=torch.Generator().manual_seed(5)).to(gpu_device)
+
+    def via_oracle(method_, q, k, v, *a, **kw):                          # the reference-shaped cache, built on the CPU
+        r = cpu_compress.oracle_compress(method_, q.cpu() if q is not None else None, k.cpu(), v.cpu(), *a, **kw)
+        return tuple(x.to(gpu_device) if torch.is_tensor(x) else x for x in r)
+    outs = {}
+    try:
+        mp.replace_llama(method)
+        for layer in model.model.layers:
+            for name, val in (("window_size", 8), ("max_capacity_prompt", 72), ("kernel_size", 7), ("pooling", "maxpool")):
+                setattr(layer.self_attn.config, name, val)
+        for mode in ("fused", "oracle"):
+            if mode == "oracle":
+                monkeypatch.setattr(pu, "DECODE_KERNEL", False)
+                monkeypatch.setattr(pu, "BATCH_LAYERS", False)
+                monkeypatch.setattr(kvc, "compress", via_oracle)
+            with torch.no_grad():
+                outs[mode] = model.generate(ids, max_new_tokens=6, do_sample=False, use_cache=True, return_dict_in_generate=True,
+                                            output_scores=True)
+    finally:
+        mp.replace_llama("fullkv")
+    assert torch.equal(outs["fused"].sequences, outs["oracle"].sequences)
+    for a, b in zip(outs["fused"].scores, outs["oracle"].scores):
+        assert float((a.float() - b.float()).abs().max()) <= 3e-2 * float(b.float().abs().max())
+    for la, lb in zip(outs["fused"].past_key_values.layers, outs["oracle"].past_key_values.layers):
+        assert la._split and not lb._split                               # (a) really took the split form, (b) the expanded one
+        assert torch.equal(la._kbuf[:, :, :la._stored], lb._kbuf[:, :, :la._stored])      # same compressed prompt, byte for byte
+        assert la.keys.shape == lb.keys.shape and la.get_seq_length() == lb.get_seq_length() == 505
