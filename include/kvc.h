@@ -47,7 +47,10 @@ typedef enum kvc_method {      /* which update_kv is being replaced */
     KVC_SNAPKV = 0,            /* pyramidkv_utils.py:306-347 */
     KVC_PYRAMIDKV = 1,         /* :197-283 — same kernels, caller passes the per-layer k (kvc_pyramid_k) */
     KVC_H2O = 2,               /* :533-575 — all q_len query rows, no pooling */
-    KVC_STREAMINGLLM = 3       /* :595-620 — no scoring: first k + last window tokens */
+    KVC_STREAMINGLLM = 3,      /* :595-620 — no scoring: first k + last window tokens */
+    KVC_ADAKV = 4,             /* :622-757 — window-MEAN scores, per-head budgets from a global top-(H*base), ragged cache:
+                                  kvc_ragged_* entry points only (k = base capacity = max_capacity_prompt - W) */
+    KVC_HEADKV = 5             /* :760-878 — the same with per-head budgets given by the caller */
 } kvc_method;
 
 typedef enum kvc_dtype { KVC_BF16 = 0, KVC_FP16 = 1, KVC_FP32 = 2 } kvc_dtype;
@@ -195,6 +198,40 @@ typedef struct kvc_decode_params {
 
 int kvc_decode_step(const kvc_decode_params* p, const void* q, const void* k_new, const void* v_new,
                     const void* k_prefix, const void* v_prefix, void* k_tail, void* v_tail, void* out, void* hip_stream);
+
+/* ---- AdaKV / HeadKV: per-head budgets, ragged ("flattened") cache -----------------------------------
+ * Replaces AdaKVCluster.update_kv (pyramidkv_utils.py:674-757), HeadKVCluster.update_kv (:813-878) and, at decode, the
+ * repo's native update_flatten_view (csrc/csrc/cuda_api.cu:12-85) + flash_attn_varlen_func (llama_model.py:2363-2390).
+ * p->method = KVC_ADAKV or KVC_HEADKV, p->k = base capacity (max_capacity_prompt - window), tie order of the per-head sort
+ * exactly torch-CPU's (libstdc++ std::sort).  Three calls, all enqueue-only:
+ *   kvc_ragged_plan     scores (window mean + pooling, :647-672) into the workspace; AdaKV: caps_out[b][h] = rows head h keeps
+ *                       (device int32; flags_out[b][0] = 1 if values equal to the global threshold span several heads and
+ *                       had to be shared out in flattened order — the one place where torch's partial_sort tie order is not
+ *                       reproduced).  HeadKV: scores only (the caller owns the capacities).
+ *   — the host reads the capacities (the reference's own metadata are host integers, :721-741) and lays out the flat cache:
+ *     seg_off[b*H + h] = first row of head h, any spare rows behind a head are for in-place decode appends —
+ *   kvc_ragged_compact  per head the first caps[h] indices of its descending sort + the W window rows, K and V, into
+ *                       k_flat / v_flat at seg_off[h]; idx_out (nullable) receives the kept indices [b*H][idx_stride].
+ *   kvc_ragged_decode_step  appends the step's K/V rows behind every head's segment (once per QUERY head, like the
+ *                       reference's flattened cache) and attends over the segment: rows [0, seg_len[h] + appended + i + 1).
+ * Workspace: kvc_ragged_workspace_bytes(p) for plan + compact (the same buffer, same stream). */
+size_t kvc_ragged_workspace_bytes(const kvc_params* p);
+int kvc_ragged_plan(const kvc_params* p, const void* q, const void* k, float floor_ratio, int normalize,
+                    int32_t* caps_out, int32_t* flags_out, void* scores_out, void* workspace, size_t workspace_bytes, void* hip_stream);
+int kvc_ragged_compact(const kvc_params* p, const void* k, const void* v, const int32_t* caps, const int64_t* seg_off, int rows_max,
+                       void* k_flat, void* v_flat, int64_t* idx_out, int64_t idx_stride,
+                       void* workspace, size_t workspace_bytes, void* hip_stream);
+typedef struct kvc_ragged_decode_params {
+    int32_t dtype, bsz, n_q_heads, n_kv_heads, head_dim;
+    int32_t appended;          /* rows appended to every segment since the prefill (before this call) */
+    int32_t new_rows;          /* tokens of this step */
+    float scaling;
+    int64_t q_stride_b, q_stride_h, q_stride_l;             /* q[b][h_q][i][:] */
+    int64_t new_stride_b, new_stride_h, new_stride_l;       /* k_new / v_new [b][h_kv][i][:] */
+    int64_t out_stride_b, out_stride_h, out_stride_l;       /* out[b][h_q][i][:] */
+} kvc_ragged_decode_params;
+int kvc_ragged_decode_step(const kvc_ragged_decode_params* p, const void* q, const void* k_new, const void* v_new,
+                           void* k_flat, void* v_flat, const int64_t* seg_off, const int32_t* seg_len, void* out, void* hip_stream);
 
 /* Debug/parity aid: byte offsets inside the workspace of the intermediates kvc_scores leaves behind.
  * offs[0]=logits [b][h][L][W] dtype, offs[1]=row max [b][h][W] f32, offs[2]=row sum [b][h][W] f32.

@@ -8,7 +8,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KVC_LIB_PATH", os.path.join(_HERE, "libkvc_hip.so"))   # override only for diagnostic builds
 
-SNAPKV, PYRAMIDKV, H2O, STREAMINGLLM = 0, 1, 2, 3
+SNAPKV, PYRAMIDKV, H2O, STREAMINGLLM, ADAKV, HEADKV = 0, 1, 2, 3, 4, 5
 BF16, FP16, FP32 = 0, 1, 2
 POOL_NONE, POOL_AVG, POOL_MAX = 0, 1, 2
 TIES_TORCH_CPU, TIES_CANONICAL = 0, 1
@@ -23,7 +23,8 @@ DOT_MODE = os.environ.get("KVC_DOT_MODE", "exact")      # default of every helpe
 
 EXPORTS = ("kvc_version", "kvc_last_error", "kvc_workspace_bytes", "kvc_compress", "kvc_scores", "kvc_select",
            "kvc_gather", "kvc_pyramid_k", "kvc_workspace_layout", "kvc_workspace_bytes_batch", "kvc_compress_batch",
-           "kvc_select_workspace_bytes", "kvc_decode_step")
+           "kvc_select_workspace_bytes", "kvc_decode_step", "kvc_ragged_workspace_bytes", "kvc_ragged_plan",
+           "kvc_ragged_compact", "kvc_ragged_decode_step")
 
 
 class KvcError(RuntimeError):
@@ -47,6 +48,13 @@ class DecodeParams(ctypes.Structure):
         (n, ctypes.c_int64) for n in ("q_stride_b", "q_stride_h", "q_stride_l", "new_stride_b", "new_stride_h", "new_stride_l",
                                       "prefix_stride_b", "prefix_stride_h", "tail_stride_b", "tail_stride_h",
                                       "out_stride_b", "out_stride_h", "out_stride_l")]
+
+
+class RaggedDecodeParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("dtype", "bsz", "n_q_heads", "n_kv_heads", "head_dim", "appended", "new_rows")] + [
+        ("scaling", ctypes.c_float)] + [(n, ctypes.c_int64) for n in (
+            "q_stride_b", "q_stride_h", "q_stride_l", "new_stride_b", "new_stride_h", "new_stride_l",
+            "out_stride_b", "out_stride_h", "out_stride_l")]
 
 
 _lib = None
@@ -77,6 +85,11 @@ def lib():
         L.kvc_workspace_bytes_batch.restype = sz
         L.kvc_compress_batch.argtypes = [pp, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         L.kvc_decode_step.argtypes = [ctypes.POINTER(DecodeParams)] + [vp] * 9
+        L.kvc_ragged_workspace_bytes.argtypes = [pp]
+        L.kvc_ragged_workspace_bytes.restype = sz
+        L.kvc_ragged_plan.argtypes = [pp, vp, vp, ctypes.c_float, ctypes.c_int, vp, vp, vp, vp, sz, vp]
+        L.kvc_ragged_compact.argtypes = [pp, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, ctypes.c_int64, vp, sz, vp]
+        L.kvc_ragged_decode_step.argtypes = [ctypes.POINTER(RaggedDecodeParams)] + [vp] * 9
         L.kvc_select_workspace_bytes.argtypes = [pp]
         L.kvc_select_workspace_bytes.restype = sz
         _lib = L
@@ -287,9 +300,11 @@ def decode_step(q, k_new, v_new, k_prefix, v_prefix, prefix_rows, k_tail, v_tail
     _require_gpu(q, k_new, v_new, k_prefix, v_prefix, k_tail, v_tail)
     dev = _one_device(q, k_new, v_new, k_prefix, v_prefix, k_tail, v_tail)
     q, k_new, v_new = _last_dim_contig(q), _last_dim_contig(k_new), _last_dim_contig(v_new)
+    if k_new.stride() != v_new.stride():        # K comes out of RoPE contiguous, V is the projection's transposed view
+        k_new, v_new = k_new.contiguous(), v_new.contiguous()
     b, hq, t, D = q.shape
     assert k_tail.shape[2] >= tail_rows + t and k_new.shape == v_new.shape and k_new.shape[2] == t
-    assert k_new.stride() == v_new.stride() and k_tail.stride() == v_tail.stride() and k_prefix.stride() == v_prefix.stride()
+    assert k_tail.stride() == v_tail.stride() and k_prefix.stride() == v_prefix.stride()
     for x in (k_prefix, v_prefix, k_tail, v_tail):
         assert x.stride(3) == 1 and x.stride(2) == D, "cache rows must be dense"
     out = torch.empty(b, t, hq, D, dtype=q.dtype, device=dev)
@@ -303,6 +318,71 @@ def decode_step(q, k_new, v_new, k_prefix, v_prefix, prefix_rows, k_tail, v_tail
     p.out_stride_b, p.out_stride_h, p.out_stride_l = out.stride(0), out.stride(2), out.stride(1)
     _check(_call(dev, lib().kvc_decode_step, ctypes.byref(p), _ptr(q), _ptr(k_new), _ptr(v_new), _ptr(k_prefix), _ptr(v_prefix),
                  _ptr(k_tail), _ptr(v_tail), _ptr(out), _stream(dev)))
+    return out
+
+
+def ragged_compress(method, q, k, v, window, base_capacity, kernel_size=7, pooling="maxpool", floor=0.2, normalize=True,
+                    head_capacity=None, slack=0, return_indices=False, return_scores=False, tie_mode="torch_cpu"):
+    """AdaKV / HeadKV on the GPU (kvc_ragged_plan + kvc_ragged_compact): per-head budgets and the flattened cache.
+    Returns a dict: k_flat / v_flat [rows, D] (head h at rows seg_off[h] .. seg_off[h] + lens[h], `slack` spare rows behind
+    every head), lens (host list, cap_h + W), caps / seg_off / seg_len (device), flag (AdaKV: 1 if a tie at the global
+    threshold spanned several heads), idx [b*H, max cap] and scores [b, H, n] on request.
+    One host synchronisation, where the reference has its own (the capacities become Python integers, :721-741)."""
+    _require_gpu(q, k, v)
+    q, k, v = _last_dim_contig(q), _last_dim_contig(k), _last_dim_contig(v)
+    dev = _one_device(q, k, v)
+    p = make_params(method, q, k, v, window, base_capacity, kernel_size, pooling, tie_mode)
+    b, hq, L, D = q.shape
+    heads, n = b * hq, L - window
+    nbytes = lib().kvc_ragged_workspace_bytes(ctypes.byref(p))
+    if nbytes == 0:
+        raise KvcError(ERR_INVALID, lib().kvc_last_error().decode())
+    ws = workspace(dev, nbytes)
+    sc = torch.empty(b, hq, n, dtype=q.dtype, device=dev) if return_scores else None
+    flags = torch.zeros(b, 2, dtype=torch.int32, device=dev)
+    if method == ADAKV:
+        caps = torch.empty(heads, dtype=torch.int32, device=dev)
+    else:
+        caps = torch.as_tensor(head_capacity, dtype=torch.int32).reshape(-1).to(dev)
+        assert caps.numel() == heads, "head_capacity needs one entry per (batch, head)"
+        caps = caps.clamp(max=n).contiguous()
+    _check(_call(dev, lib().kvc_ragged_plan, ctypes.byref(p), _ptr(q), _ptr(k), float(floor), int(bool(normalize)),
+                 _ptr(caps if method == ADAKV else None), _ptr(flags), _ptr(sc), _ptr(ws), nbytes, _stream(dev)))
+    caps_host = caps.cpu()                                     # the synchronisation
+    lens = (caps_host + window).tolist()
+    offs, row = [], 0
+    for ln in lens:
+        offs.append(row)
+        row += ln + slack
+    seg_off = torch.tensor(offs, dtype=torch.int64, device=dev)
+    k_flat = torch.empty(row, D, dtype=k.dtype, device=dev)
+    v_flat = torch.empty_like(k_flat)
+    cap_max = int(caps_host.max()) if heads else 0
+    idx = torch.full((heads, max(cap_max, 1)), -1, dtype=torch.int64, device=dev) if return_indices else None
+    _check(_call(dev, lib().kvc_ragged_compact, ctypes.byref(p), _ptr(k), _ptr(v), _ptr(caps), _ptr(seg_off), cap_max + window,
+                 _ptr(k_flat), _ptr(v_flat), _ptr(idx), idx.shape[1] if idx is not None else 0, _ptr(ws), nbytes, _stream(dev)))
+    return dict(k_flat=k_flat, v_flat=v_flat, lens=lens, caps=caps, seg_off=seg_off,
+                seg_len=(caps + window).to(torch.int32), flag=flags[:, 0], idx=idx, scores=sc, slack=slack)
+
+
+def ragged_decode_step(q, k_new, v_new, k_flat, v_flat, seg_off, seg_len, appended, scaling):
+    """One decode step over the ragged cache (kvc_ragged_decode_step): k_new / v_new [b, H_kv, t, D] are written behind every
+    query head's segment (row seg_off + seg_len + appended) and the attention output [b, t, H_q, D] comes back."""
+    _require_gpu(q, k_new, v_new, k_flat, v_flat)
+    dev = _one_device(q, k_new, v_new, k_flat, v_flat, seg_off, seg_len)
+    q, k_new, v_new = _last_dim_contig(q), _last_dim_contig(k_new), _last_dim_contig(v_new)
+    if k_new.stride() != v_new.stride():
+        k_new, v_new = k_new.contiguous(), v_new.contiguous()
+    b, hq, t, D = q.shape
+    out = torch.empty(b, t, hq, D, dtype=q.dtype, device=dev)
+    p = RaggedDecodeParams()
+    p.dtype, p.bsz, p.n_q_heads, p.n_kv_heads, p.head_dim = DTYPES[q.dtype], b, hq, k_new.shape[1], D
+    p.appended, p.new_rows, p.scaling = appended, t, scaling
+    p.q_stride_b, p.q_stride_h, p.q_stride_l = q.stride(0), q.stride(1), q.stride(2)
+    p.new_stride_b, p.new_stride_h, p.new_stride_l = k_new.stride(0), k_new.stride(1), k_new.stride(2)
+    p.out_stride_b, p.out_stride_h, p.out_stride_l = out.stride(0), out.stride(2), out.stride(1)
+    _check(_call(dev, lib().kvc_ragged_decode_step, ctypes.byref(p), _ptr(q), _ptr(k_new), _ptr(v_new), _ptr(k_flat), _ptr(v_flat),
+                 _ptr(seg_off), _ptr(seg_len), _ptr(out), _stream(dev)))
     return out
 
 

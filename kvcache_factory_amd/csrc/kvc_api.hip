@@ -23,7 +23,8 @@ int fail(int code, const char* fmt, ...) {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int esize_of(int dtype) { return dtype == KVC_FP32 ? 4 : 2; }
-inline bool scoring(int method) { return method == KVC_SNAPKV || method == KVC_PYRAMIDKV || method == KVC_H2O; }
+inline bool scoring(int method) { return method == KVC_SNAPKV || method == KVC_PYRAMIDKV || method == KVC_H2O || method == KVC_ADAKV || method == KVC_HEADKV; }
+inline bool ragged(int method) { return method == KVC_ADAKV || method == KVC_HEADKV; }
 
 struct Layout {
     size_t logits, pmax, psum, rowmax, rowsum, scores, idx, exact, total;   // H2O: logits = S [L][L], rowmax/rowsum = [L] per head
@@ -34,7 +35,7 @@ struct Layout {
 // Validation shared by every entry point.  `need_q`: the call reads q/k for scoring.
 int validate(const kvc_params* p, bool need_scores) {
     if (!p) return fail(KVC_ERR_INVALID, "params is NULL");
-    if (p->method < KVC_SNAPKV || p->method > KVC_STREAMINGLLM) return fail(KVC_ERR_INVALID, "unknown method %d", p->method);
+    if (p->method < KVC_SNAPKV || p->method > KVC_HEADKV) return fail(KVC_ERR_INVALID, "unknown method %d", p->method);
     if (p->dtype < KVC_BF16 || p->dtype > KVC_FP32) return fail(KVC_ERR_INVALID, "unknown dtype %d", p->dtype);
     if (p->bsz < 1 || p->n_q_heads < 1 || p->n_kv_heads < 1) return fail(KVC_ERR_INVALID, "bsz / head counts must be positive");
     if (p->n_q_heads % p->n_kv_heads) return fail(KVC_ERR_INVALID, "n_q_heads %d not a multiple of n_kv_heads %d", p->n_q_heads, p->n_kv_heads);
@@ -181,6 +182,7 @@ int enqueue_scores(const kvc_params* p, const Layout& l, const Items& it, char* 
     a.kernel_size = p->kernel_size; a.pooling = p->pooling;
     a.stage_mask = p->debug_stage_mask;
     a.fast_dot = (p->dot_mode == KVC_DOT_MFMA16 && p->dtype != KVC_FP32) ? 1 : 0;
+    a.window_mean = ragged(p->method) ? 1 : 0;              // calcul_attn_sore (:660): .mean(dim=-2)
     a.dbg = nullptr;
 #if defined(KVC_STAMPS)
     a.dbg = reinterpret_cast<unsigned long long*>(it.scores[0]);   // diagnostic build: stamps land in scores_out
@@ -215,8 +217,13 @@ kvc::GatherArgs gather_args(const kvc_params* p, const Items& it, int which, boo
 
 // A7 for every item (+ A8 in the same kernel when `fuse`).  exact_scratch: n_items regions for the exact tie mode.
 int enqueue_select(const kvc_params* p, const Items& it, bool fuse, void* exact_scratch, hipStream_t st) {
-    if (it.k_max > 16384) return fail(KVC_ERR_UNSUPPORTED, "k=%d > 16384: the LDS sort of the selected set is not built for it", it.k_max);
-    if (p->q_len - p->window > 65536) return fail(KVC_ERR_UNSUPPORTED, "more than 65536 candidates per head not built");
+    const int n_sel = p->q_len - p->window;
+    if (p->tie_mode == KVC_TIES_CANONICAL) {
+        if (it.k_max > 16384) return fail(KVC_ERR_UNSUPPORTED, "tie_mode canonical: k=%d > 16384 (the LDS sort of the selected set) not built", it.k_max);
+        if (n_sel > 65536) return fail(KVC_ERR_UNSUPPORTED, "tie_mode canonical: more than 65536 candidates per head not built (torch_cpu has no such limit)");
+    } else if ((int64_t)it.k_max * 64 <= (int64_t)n_sel && it.k_max > 18000) {
+        return fail(KVC_ERR_UNSUPPORTED, "tie_mode torch_cpu: a partial_sort heap of k=%d does not fit in LDS", it.k_max);
+    }
     kvc::SelectArgs s;
     std::memset(&s, 0, sizeof(s));
     for (int i = 0; i < it.n; ++i) { s.scores.p[i] = it.scores[i]; s.idx.p[i] = it.idx[i]; s.k.v[i] = it.keep[i]; }
@@ -478,6 +485,169 @@ __attribute__((visibility("default"))) int kvc_decode_step(const kvc_decode_para
     return hip_ok("decode step launch");
 }
 
+// ---- AdaKV / HeadKV -------------------------------------------------------------------------------------------------------
+namespace {
+struct RaggedLayout { size_t ratio, idx, sort, flat, top, sel, total; };
+RaggedLayout ragged_carve(const kvc_params* p, const Layout& l) {
+    RaggedLayout r;
+    const size_t heads = (size_t)p->bsz * p->n_q_heads, n = (size_t)(p->q_len - p->window);
+    size_t off = l.total;
+    r.ratio = off; off = align_up(off + heads * 4, 256);
+    r.idx = off;   off = align_up(off + heads * n * 8, 256);
+    r.sort = off;  off = align_up(off + kvc::sort_prefix_scratch_bytes((int)heads, (int)n), 256);
+    r.flat = r.top = r.sel = off;
+    if (p->method == KVC_ADAKV && p->tie_mode == KVC_TIES_TORCH_CPU) {        // the reference's own flattened top-(H*base)
+        const size_t n_tot = (size_t)p->n_q_heads * n, k_tot = (size_t)p->n_q_heads * (size_t)p->k;
+        r.flat = off; off = align_up(off + (size_t)p->bsz * n_tot * esize_of(p->dtype), 256);
+        r.top = off;  off = align_up(off + (size_t)p->bsz * k_tot * 8, 256);
+        r.sel = off;  off = align_up(off + kvc::select_exact_scratch_bytes(p->bsz, (int)n_tot, (int)k_tot), 256);
+    }
+    r.total = off;
+    return r;
+}
+int ragged_check(const kvc_params* p) {
+    if (int rc = validate(p, true)) return rc;
+    if (!ragged(p->method)) return fail(KVC_ERR_INVALID, "kvc_ragged_*: method must be KVC_ADAKV or KVC_HEADKV");
+    if (p->n_q_heads > 256) return fail(KVC_ERR_UNSUPPORTED, "more than 256 heads");
+    return KVC_OK;
+}
+}  // namespace
+
+__attribute__((visibility("default"))) size_t kvc_ragged_workspace_bytes(const kvc_params* p) {
+    if (ragged_check(p) != KVC_OK) return 0;
+    g_err[0] = 0;
+    kvc_params pk = *p;
+    pk.k = 0;
+    return ragged_carve(p, carve(&pk)).total;
+}
+
+__attribute__((visibility("default"))) int kvc_ragged_plan(const kvc_params* p, const void* q, const void* k, float floor_ratio,
+                                                           int normalize, int32_t* caps_out, int32_t* flags_out, void* scores_out,
+                                                           void* workspace, size_t workspace_bytes, void* hip_stream) {
+    if (int rc = ragged_check(p)) return rc;
+    if (!q || !k) return fail(KVC_ERR_INVALID, "q and k must be non-NULL");
+    const int es = esize_of(p->dtype);
+    if (int rc = check_strides("q", es, p->q_stride_b, p->q_stride_h, p->q_stride_l, q)) return rc;
+    if (int rc = check_strides("k", es, p->k_stride_b, p->k_stride_h, p->k_stride_l, k)) return rc;
+    kvc_params pk = *p;
+    pk.k = 0;
+    const Layout l = carve(&pk);
+    const RaggedLayout r = ragged_carve(p, l);
+    if (!workspace || ((uintptr_t)workspace) % 256 || workspace_bytes < r.total)
+        return fail(KVC_ERR_WORKSPACE, "kvc_ragged_plan needs %zu bytes of 256-byte aligned workspace", r.total);
+    char* ws = static_cast<char*>(workspace);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    Items it;
+    std::memset(&it, 0, sizeof(it));
+    it.n = 1; it.q[0] = q; it.k[0] = k; it.scores[0] = ws + l.scores;
+    if (int rc = enqueue_scores(&pk, l, it, ws, st)) return rc;
+    const size_t heads = (size_t)p->bsz * p->n_q_heads, n = (size_t)(p->q_len - p->window);
+    if (scores_out) {
+        if (hipMemcpyAsync(scores_out, ws + l.scores, heads * n * es, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return fail(KVC_ERR_HIP, "copy of the scores failed");
+    }
+    if (p->method == KVC_ADAKV) {
+        if (!caps_out) return fail(KVC_ERR_INVALID, "caps_out must be non-NULL for AdaKV");
+        if (p->k < 1 || (size_t)p->k > n) return fail(KVC_ERR_INVALID, "base capacity k=%d outside [1, q_len - window]", p->k);
+        if (!(floor_ratio >= 0.0f && floor_ratio <= 1.0f)) return fail(KVC_ERR_INVALID, "floor_ratio outside [0, 1]");
+        kvc::RaggedArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.scores = ws + l.scores;
+        a.ratio = reinterpret_cast<float*>(ws + r.ratio);
+        a.caps = caps_out;
+        a.flags = flags_out ? flags_out : reinterpret_cast<int32_t*>(ws + r.sort);     // (scratch slot when not wanted)
+        a.n = (int)n; a.heads_per_batch = p->n_q_heads; a.base = p->k; a.normalize = normalize ? 1 : 0;
+        a.floor_capacity = (int)((double)p->k * (double)floor_ratio);                 // int(base_capacity * floor_ratio), :632
+        a.mix = (float)(1.0 - (double)floor_ratio);
+        if (p->tie_mode == KVC_TIES_TORCH_CPU) {
+            // exactly the reference: every head's whole descending sort, the normalised values in that order, torch-CPU's
+            // top-(H*base) over the flattened array (libstdc++ partial_sort / nth_element: one wave walks it), counts per head
+            const int64_t n_tot = (int64_t)p->n_q_heads * (int64_t)n, k_tot = (int64_t)p->n_q_heads * p->k;
+            if (n_tot > 0x7fffffff) return fail(KVC_ERR_UNSUPPORTED, "flattened score array too long");
+            kvc::RaggedSortArgs sa;
+            sa.scores = ws + l.scores; sa.caps = nullptr; sa.idx_out = reinterpret_cast<int64_t*>(ws + r.idx);
+            sa.n = (int)n; sa.heads = (int)heads; sa.out_stride = (int)n;
+            if (int rc = kvc::launch_sort_prefix(sa, p->dtype, ws + r.sort, st)) return fail(rc, "sort launch failed");
+            if (a.normalize) kvc::launch_ragged_head_stats(a, p->dtype, p->bsz, st);
+            kvc::launch_ragged_flatten(a, p->dtype, p->bsz, sa.idx_out, ws + r.flat, st);
+            kvc_params ps = *p;
+            ps.bsz = p->bsz; ps.n_q_heads = 1; ps.n_kv_heads = 1; ps.q_len = (int)n_tot + p->window; ps.k = (int)k_tot;
+            Items sel;
+            std::memset(&sel, 0, sizeof(sel));
+            sel.n = 1; sel.scores[0] = ws + r.flat; sel.idx[0] = reinterpret_cast<int64_t*>(ws + r.top); sel.keep[0] = (int)k_tot; sel.k_max = (int)k_tot;
+            if (int rc = enqueue_select(&ps, sel, false, ws + r.sel, st)) return rc;
+            kvc::launch_ragged_recount(a, p->bsz, reinterpret_cast<const int64_t*>(ws + r.top), st);
+        } else if (int rc = kvc::launch_ragged_plan(a, p->dtype, p->bsz, st)) {
+            return fail(rc, "ragged plan launch failed");
+        }
+    }
+    return hip_ok("ragged plan launch");
+}
+
+__attribute__((visibility("default"))) int kvc_ragged_compact(const kvc_params* p, const void* k, const void* v, const int32_t* caps,
+                                                              const int64_t* seg_off, int rows_max, void* k_flat, void* v_flat,
+                                                              int64_t* idx_out, int64_t idx_stride, void* workspace,
+                                                              size_t workspace_bytes, void* hip_stream) {
+    if (int rc = ragged_check(p)) return rc;
+    if (!k || !v || !caps || !seg_off || !k_flat || !v_flat) return fail(KVC_ERR_INVALID, "k, v, caps, seg_off and the flat buffers must be non-NULL");
+    const int es = esize_of(p->dtype);
+    if (int rc = check_strides("k", es, p->k_stride_b, p->k_stride_h, p->k_stride_l, k)) return rc;
+    if (int rc = check_strides("v", es, p->v_stride_b, p->v_stride_h, p->v_stride_l, v)) return rc;
+    if (((uintptr_t)k_flat) % 16 || ((uintptr_t)v_flat) % 16) return fail(KVC_ERR_ALIGNMENT, "flat buffers not 16-byte aligned");
+    kvc_params pk = *p;
+    pk.k = 0;
+    const Layout l = carve(&pk);
+    const RaggedLayout r = ragged_carve(p, l);
+    if (!workspace || ((uintptr_t)workspace) % 256 || workspace_bytes < r.total)
+        return fail(KVC_ERR_WORKSPACE, "kvc_ragged_compact needs %zu bytes of 256-byte aligned workspace", r.total);
+    const int heads = p->bsz * p->n_q_heads, n = p->q_len - p->window;
+    if (rows_max < p->window || rows_max > n + p->window) return fail(KVC_ERR_INVALID, "rows_max %d outside [window, q_len]", rows_max);
+    if (idx_out && idx_stride < rows_max - p->window) return fail(KVC_ERR_INVALID, "idx_stride smaller than the largest capacity");
+    char* ws = static_cast<char*>(workspace);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    kvc::RaggedSortArgs sa;
+    sa.scores = ws + l.scores; sa.caps = caps;
+    sa.idx_out = idx_out ? idx_out : reinterpret_cast<int64_t*>(ws + r.idx);
+    sa.n = n; sa.heads = heads; sa.out_stride = idx_out ? (int)idx_stride : n;
+    // (AdaKV with torch_cpu ties: kvc_ragged_plan left every head's whole sort in the workspace — its prefix is the answer)
+    const bool presorted = p->method == KVC_ADAKV && p->tie_mode == KVC_TIES_TORCH_CPU && !idx_out;
+    if (!presorted)
+        if (int rc = kvc::launch_sort_prefix(sa, p->dtype, ws + r.sort, st)) return fail(rc, "sort prefix launch failed");
+    kvc::RaggedGatherArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.k = k; g.v = v; g.k_flat = k_flat; g.v_flat = v_flat;
+    g.idx = sa.idx_out; g.idx_stride = sa.out_stride; g.caps = caps; g.seg_off = seg_off;
+    g.k_stride_b = p->k_stride_b; g.k_stride_h = p->k_stride_h; g.k_stride_l = p->k_stride_l;
+    g.v_stride_b = p->v_stride_b; g.v_stride_h = p->v_stride_h; g.v_stride_l = p->v_stride_l;
+    g.n_q_heads = p->n_q_heads; g.group = p->n_q_heads / p->n_kv_heads; g.q_len = p->q_len; g.window = p->window;
+    g.esize = es; g.row_bytes = p->head_dim * es;
+    kvc::launch_ragged_gather(g, rows_max, heads, st);
+    return hip_ok("ragged compact launch");
+}
+
+__attribute__((visibility("default"))) int kvc_ragged_decode_step(const kvc_ragged_decode_params* p, const void* q, const void* k_new,
+                                                                  const void* v_new, void* k_flat, void* v_flat, const int64_t* seg_off,
+                                                                  const int32_t* seg_len, void* out, void* hip_stream) {
+    if (!p) return fail(KVC_ERR_INVALID, "params is NULL");
+    if (p->dtype < KVC_BF16 || p->dtype > KVC_FP32) return fail(KVC_ERR_INVALID, "unknown dtype %d", p->dtype);
+    if (p->bsz < 1 || p->n_q_heads < 1 || p->n_kv_heads < 1 || p->n_q_heads % p->n_kv_heads) return fail(KVC_ERR_INVALID, "bsz / head counts invalid");
+    if (p->head_dim != 64 && p->head_dim != 128) return fail(KVC_ERR_UNSUPPORTED, "decode kernels are built for head_dim 64 and 128, got %d", p->head_dim);
+    if (p->appended < 0 || p->new_rows < 1) return fail(KVC_ERR_INVALID, "row counts invalid");
+    if (!q || !k_new || !v_new || !k_flat || !v_flat || !seg_off || !seg_len || !out) return fail(KVC_ERR_INVALID, "a pointer is NULL");
+    const int es = esize_of(p->dtype);
+    kvc::RaggedDecodeArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.q = q; a.k_new = k_new; a.v_new = v_new; a.k_flat = k_flat; a.v_flat = v_flat; a.out = out; a.seg_off = seg_off; a.seg_len = seg_len;
+    a.q_stride_b = p->q_stride_b; a.q_stride_h = p->q_stride_h; a.q_stride_l = p->q_stride_l;
+    a.new_stride_b = p->new_stride_b; a.new_stride_h = p->new_stride_h; a.new_stride_l = p->new_stride_l;
+    a.out_stride_b = p->out_stride_b; a.out_stride_h = p->out_stride_h; a.out_stride_l = p->out_stride_l;
+    a.n_q_heads = p->n_q_heads; a.group = p->n_q_heads / p->n_kv_heads; a.appended = p->appended; a.new_rows = p->new_rows;
+    a.esize = es; a.row_bytes = p->head_dim * es; a.scaling = p->scaling;
+    if (int rc = kvc::launch_ragged_decode(a, p->dtype, p->head_dim, p->bsz * p->n_q_heads, static_cast<hipStream_t>(hip_stream)))
+        return fail(rc, "no ragged decode kernel for dtype %d head_dim %d", p->dtype, p->head_dim);
+    return hip_ok("ragged decode launch");
+}
+
 __attribute__((visibility("default"))) int kvc_compress(const kvc_params* p, const void* q, const void* k, const void* v,
                                                         void* k_out, void* v_out, int64_t* idx_out, void* scores_out,
                                                         void* workspace, size_t workspace_bytes, void* hip_stream) {
@@ -488,6 +658,7 @@ __attribute__((visibility("default"))) int kvc_compress(const kvc_params* p, con
     it.n = 1;
     it.q[0] = q; it.k[0] = k; it.v[0] = v; it.k_out[0] = k_out; it.v_out[0] = v_out;
     it.idx[0] = idx_out; it.scores[0] = scores_out; it.keep[0] = p->k; it.out_stride_h[0] = p->out_stride_h;
+    if (ragged(p->method)) return fail(KVC_ERR_INVALID, "AdaKV / HeadKV produce a ragged cache: use the kvc_ragged_* entry points");
     return run_items(p, it, workspace, workspace_bytes, static_cast<hipStream_t>(hip_stream));
 }
 

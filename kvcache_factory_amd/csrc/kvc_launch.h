@@ -33,6 +33,7 @@ struct ScoreArgs {
     int bsz, n_q_heads, n_kv_heads, group, q_len, window;
     int n_tiles, kernel_size, pooling;
     int fast_dot;          // 1: packed bf16/fp16 MFMA scan (tolerance mode), 0: exact f32 fmaf-chain MFMA
+    int window_mean;       // 1: the window rows are averaged (AdaKV / HeadKV, .mean(dim=-2)) instead of summed
     int stage_mask;        // bits 0-2: 0 = all, else bit0 logits, bit1 rowsum, bit2 pool (profiling aid); bit3 / bit4: force the split / fused softmax path
     float sqrt_d;
     unsigned long long* dbg;   // diagnostic stamps (KVC_STAMPS builds only), else null
@@ -74,6 +75,39 @@ struct SelectArgs {
 
 struct GatherPair { GatherArgs t[2]; int count; };    // K and V compacted by one launch
 
+struct RaggedSortArgs {    // sort_prefix_kernel (AdaKV / HeadKV)
+    const void* scores;    // [heads][n] dtype
+    const int32_t* caps;   // [heads] device: how many leading indices of the descending sort each head keeps
+    int64_t* idx_out;      // [heads][out_stride]
+    int n, heads, out_stride;
+};
+
+struct RaggedArgs {        // ragged_head_stats_kernel / ragged_budget_kernel (AdaKV budgets)
+    const void* scores;    // [bsz][H][n] dtype (pooled window-mean scores)
+    float* ratio;          // [bsz][H] fp32 scratch: sum(top base) / sum(all) per head, dtype-rounded
+    int32_t* caps;         // [bsz][H] out: rows each head keeps (without the window)
+    int32_t* flags;        // [bsz][2] out: [0] cross-head tie at the global threshold, [1] slots given to threshold-valued scores
+    int n, heads_per_batch, base, floor_capacity, normalize;
+    float mix;             // (float)(1 - floor_ratio)
+};
+
+struct RaggedGatherArgs {  // ragged_gather_kernel: K and V rows -> the flat cache
+    const void* k; const void* v; void* k_flat; void* v_flat;
+    const int64_t* idx;    // [bsz*H][idx_stride] sorted indices (sort_prefix_kernel)
+    const int32_t* caps;   // [bsz*H]
+    const int64_t* seg_off;    // [bsz*H] first row of each head's segment in the flat cache
+    int64_t k_stride_b, k_stride_h, k_stride_l, v_stride_b, v_stride_h, v_stride_l;
+    int idx_stride, n_q_heads, group, q_len, window, row_bytes, esize;
+};
+
+struct RaggedDecodeArgs {  // one decode step over the ragged cache
+    const void* q; const void* k_new; const void* v_new; void* k_flat; void* v_flat; void* out;
+    const int64_t* seg_off; const int32_t* seg_len;      // [bsz*H]: segment start (rows) and rows after the prefill
+    int64_t q_stride_b, q_stride_h, q_stride_l, new_stride_b, new_stride_h, new_stride_l, out_stride_b, out_stride_h, out_stride_l;
+    int n_q_heads, group, appended, new_rows, esize, row_bytes;
+    float scaling;
+};
+
 struct DecodeArgs {        // one decode step over the compacted cache (kvc_decode.hip); strides in elements
     const void* q; const void* k_new; const void* v_new;
     const void* k_prefix; const void* v_prefix;       // [b][Hq][prefix rows][D]
@@ -110,6 +144,14 @@ int launch_select_exact(const SelectArgs& a, int dtype, void* scratch, hipStream
 size_t select_exact_scratch_bytes(int heads, int n, int k);     // per item
 int launch_gather(const GatherPair& p, hipStream_t st);
 int launch_decode_step(const DecodeArgs& a, int dtype, int head_dim, hipStream_t st);
+int launch_sort_prefix(const RaggedSortArgs& a, int dtype, void* scratch, hipStream_t st);
+size_t sort_prefix_scratch_bytes(int heads, int n);
+int launch_ragged_plan(const RaggedArgs& a, int dtype, int bsz, hipStream_t st);
+int launch_ragged_head_stats(const RaggedArgs& a, int dtype, int bsz, hipStream_t st);
+int launch_ragged_flatten(const RaggedArgs& a, int dtype, int bsz, const int64_t* idx, void* flat, hipStream_t st);
+int launch_ragged_recount(const RaggedArgs& a, int bsz, const int64_t* top, hipStream_t st);
+int launch_ragged_gather(const RaggedGatherArgs& a, int rows_max, int heads, hipStream_t st);
+int launch_ragged_decode(const RaggedDecodeArgs& a, int dtype, int head_dim, int heads, hipStream_t st);
 static constexpr int kFuseGatherMaxK = 512;   // select_kernel gathers the rows itself up to this k
 
 }  // namespace kvc

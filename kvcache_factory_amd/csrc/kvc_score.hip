@@ -704,7 +704,8 @@ __global__ __launch_bounds__(256) void pool_kernel(const ScoreArgs a) {
                     cs.add(rnd<DT>(exp_u20(x[w] - m[w]) * rinv[w]));
                 }
             }
-            sv = rnd<DT>(cs.result());
+            // .sum(dim=-2) rounds the fp32 cascade once; .mean(dim=-2) (AdaKV / HeadKV) is cast_fp32 -> sum -> div_(W) -> cast
+            sv = rnd<DT>(a.window_mean ? cs.result() / (float)W : cs.result());
         }
         s_tile[t] = sv;
     }
@@ -874,7 +875,7 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
             cs.add(rnd<DT>(pr.x));
             cs.add(rnd<DT>(pr.y));
         }
-        return rnd<DT>(cs.result());
+        return rnd<DT>(a.window_mean ? cs.result() / (float)W : cs.result());
     };
     if constexpr (KEEP > 0) {
 #pragma unroll

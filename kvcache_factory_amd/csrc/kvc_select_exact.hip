@@ -430,6 +430,57 @@ struct WaveSel {
             }
         }
     }
+    // (caps == nullptr in the kernel below: the whole sort.)
+    // The first `want` elements of std::sort(first, last), written to out[0..want) as indices (AdaKV / HeadKV keep a prefix of
+    // the head's full descending sort, pyramidkv_utils.py:702-724).  std::sort = introsort loop + final insertion sort: the
+    // loop only ever splits ranges, and a range that starts at or beyond `want` can be left alone — everything in it sorts
+    // behind every element to its left, it is never mixed with them again, and the final insertion sort moves an element
+    // by at most 15 places inside its own leaf range.  So: partition exactly as libstdc++ does, descend only into ranges
+    // that start before `want`, then place the elements below want + 16 by the stable-insertion count of sort_to().
+    __device__ void sort_prefix_to(int first, int last, int want, int* stack, int64_t* out) {
+        if (first == last || want <= 0) return;
+        Arr A{arr};
+        int sp = 0;
+        int f = first, l = last, d = lg_(last - first) * 2;
+        while (true) {
+            while (l - f > 16) {
+                if (d == 0) {
+                    heap_select_(A, f, l, l);
+                    sort_heap_(A, f, l);
+                    __syncthreads();
+                    break;
+                }
+                --d;
+                const int cut = partition_pivot(f, l);
+                if (cut < first + want) {                                  // the right part still reaches into the prefix
+                    if (lane == 0) { stack[3 * sp] = cut; stack[3 * sp + 1] = l; stack[3 * sp + 2] = d; }
+                    ++sp;
+                }
+                l = cut;
+            }
+            if (sp == 0) break;
+            --sp;
+            __syncthreads();
+            f = uni(stack[3 * sp]); l = uni(stack[3 * sp + 1]); d = uni(stack[3 * sp + 2]);
+        }
+        __syncthreads();
+        const int lim = first + want + 16 < last ? first + want + 16 : last;
+        for (int base = first; base < lim; base += 64) {
+            const int i = base + lane;
+            if (i < lim) {
+                const u64 v = arr[i];
+                const uint32_t ki = key(v);
+                int pos = i;
+#pragma unroll 5
+                for (int dlt = 1; dlt < 16; ++dlt) {
+                    const int jb = i - dlt, ja = i + dlt;
+                    if (jb >= first && key(arr[jb]) < ki) --pos;
+                    if (ja < last && key(arr[ja]) > ki) ++pos;
+                }
+                if (pos - first < want) out[pos - first] = (int64_t)(v & 0xffffffffull);
+            }
+        }
+    }
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -666,10 +717,15 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const SelectArgs a, u6
     int64_t* out = reinterpret_cast<int64_t*>(const_cast<void*>(a.idx.p[item])) + (int64_t)head * k;
     const bool use_partial_sort = (int64_t)k * 64 <= (int64_t)n;
 
+    // (key << 16 | index) nodes need indices below 65536; longer rows (128k contexts, AdaKV's flattened [H * n] array) take
+    // the 64-bit nodes
     if (use_partial_sort && k <= kWaveHeapMaxK) {
-        if constexpr (Key<DT>::bits == 16) partial_sort_wave<DT, uint32_t>(s, n, k, reinterpret_cast<uint32_t*>(lds_arr), out);   // n <= 65536
-        else partial_sort_wave<DT, u64>(s, n, k, lds_arr, out);
-    } else if (use_partial_sort && k <= kWaveHeap9MaxK && Key<DT>::bits == 16) {
+        if (Key<DT>::bits == 16 && n <= 65536) {
+            if constexpr (Key<DT>::bits == 16) partial_sort_wave<DT, uint32_t>(s, n, k, reinterpret_cast<uint32_t*>(lds_arr), out);
+        } else {
+            partial_sort_wave<DT, u64>(s, n, k, lds_arr, out);
+        }
+    } else if (use_partial_sort && k <= kWaveHeap9MaxK && Key<DT>::bits == 16 && n <= 65536) {
         if constexpr (Key<DT>::bits == 16) partial_sort_wave9<DT>(s, n, k, reinterpret_cast<uint32_t*>(lds_arr), out);
     } else if (use_partial_sort) {
         // heap of the first k in LDS; the tail is streamed 64 at a time
@@ -753,7 +809,8 @@ static int launch_exact_t(const SelectArgs& a, void* scratch, hipStream_t st) {
     // being sorted; plus 4 KB of lists for small partitions — unless that costs a resident wave per CU (160 KB of LDS, one
     // wave = one workgroup here: these kernels are latency-bound, a second round of workgroups doubles their time)
     size_t body = (in_lds && any_nth) ? (size_t)a.n * 8 : (size_t)a.k_max * 8;
-    if (body < kWaveHeap9Lds) body = kWaveHeap9Lds;                 // (>= kWaveHeapLds)
+    if (body < kWaveHeap9Lds) body = kWaveHeap9Lds;
+    if (body < kWaveHeapLds) body = kWaveHeapLds;                   // 64-bit nodes (fp32, or n > 65536)
     const bool small_lists = any_nth && (160 * 1024) / (1152 + body + kSmallListBytes) == (160 * 1024) / (1152 + body) &&
                              1152 + body + kSmallListBytes <= 150 * 1024;
     if (small_lists) body += kSmallListBytes;
@@ -764,6 +821,57 @@ static int launch_exact_t(const SelectArgs& a, void* scratch, hipStream_t st) {
     hipLaunchKernelGGL((select_exact_kernel<DT>), dim3((unsigned)a.heads, (unsigned)a.n_items), dim3(64), lds, st, a,
                        reinterpret_cast<u64*>(scratch), in_lds | (small_lists ? 2 : 0));
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// sort_prefix_kernel (AdaKV / HeadKV): out[head][0..caps[head]) = the first caps[head] indices of
+// scores[head].sort(descending=True) as torch-CPU produces them (libstdc++ std::sort, value-only comparator).
+// grid = (heads), block = 64.  The (key, index) array lives in LDS (n <= 18000) or in `gscratch` ([heads][n] u64).
+// ---------------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(64) void sort_prefix_kernel(const RaggedSortArgs a, u64* gscratch, int arr_in_lds) {
+    typedef typename Dt<DT>::raw raw;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* stack = reinterpret_cast<int*>(smem);                        // 3 * 96 ints
+    u64* lds_arr = reinterpret_cast<u64*>(smem + 1152);
+    const int lane = threadIdx.x, head = blockIdx.x, n = a.n;
+    int want = a.caps ? a.caps[head] : n;
+    want = want < 0 ? 0 : (want > n ? n : want);
+    const raw* s = reinterpret_cast<const raw*>(a.scores) + (int64_t)head * n;
+    int64_t* out = a.idx_out + (int64_t)head * a.out_stride;
+    const int64_t per_head = (arr_in_lds ? 0 : (int64_t)n) + (n / 2 + 2);
+    u64* const hs = gscratch + (int64_t)head * per_head;
+    u64* arr = arr_in_lds ? lds_arr : hs;
+    int* const lists = reinterpret_cast<int*>(hs + (arr_in_lds ? 0 : n));
+    int* const small = arr_in_lds ? reinterpret_cast<int*>(lds_arr + n) : reinterpret_cast<int*>(lds_arr);
+    for (int i = lane; i < n; i += 64) arr[i] = ((u64)Key<DT>::of(s[i]) << 32) | (uint32_t)i;
+    __syncthreads();
+    WaveSel S{arr, lists, lists + (n / 2 + 2), small, lane};
+    S.sort_prefix_to(0, n, want, stack, out);
+}
+
+size_t sort_prefix_scratch_bytes(int heads, int n) {
+    return (size_t)heads * ((n <= 18000 ? 0 : (size_t)n) + (size_t)(n / 2 + 2)) * 8;
+}
+
+template <int DT>
+static int launch_sort_prefix_t(const RaggedSortArgs& a, void* scratch, hipStream_t st) {
+    const int in_lds = a.n <= 18000;
+    const size_t lds = 1152 + (in_lds ? (size_t)a.n * 8 : 0) + kSmallListBytes;
+    if (!scratch) return KVC_ERR_WORKSPACE;
+    static LdsCache lds_cache = {};
+    if (ensure_lds(reinterpret_cast<const void*>(&sort_prefix_kernel<DT>), lds, lds_cache) != 0) return KVC_ERR_HIP;
+    hipLaunchKernelGGL((sort_prefix_kernel<DT>), dim3((unsigned)a.heads), dim3(64), lds, st, a, reinterpret_cast<u64*>(scratch), in_lds);
+    return 0;
+}
+
+int launch_sort_prefix(const RaggedSortArgs& a, int dtype, void* scratch, hipStream_t st) {
+    switch (dtype) {
+        case KVC_BF16: return launch_sort_prefix_t<KVC_BF16>(a, scratch, st);
+        case KVC_FP16: return launch_sort_prefix_t<KVC_FP16>(a, scratch, st);
+        case KVC_FP32: return launch_sort_prefix_t<KVC_FP32>(a, scratch, st);
+    }
+    return KVC_ERR_INVALID;
 }
 
 int launch_select_exact(const SelectArgs& a, int dtype, void* scratch, hipStream_t st) {

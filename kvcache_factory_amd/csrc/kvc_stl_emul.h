@@ -206,4 +206,39 @@ KVC_HD inline void sort_(AT& A, int first, int last, int* stack /*LDS, 3 ints pe
     }
 }
 
+// The first `want` elements of std::sort(first, last) as indices in out[0..want) (AdaKV / HeadKV keep a prefix of a head's full
+// descending sort).  Scalar statement of what WaveSel::sort_prefix_to (kvc_select_exact.hip) does lane-parallel: the
+// introsort loop descends only into ranges that start before first + want — a range further right is never mixed with
+// anything to its left again — and every element below first + want + 16 is placed by its stable-insertion count
+// (insertion sort is stable and the loop leaves ordered runs of at most 16).  Checked against std::sort by tests/stl_emul_host.cpp.
+template <class AT>
+KVC_HD inline void sort_prefix_(AT& A, int first, int last, int want, int* stack, int64_t* out) {
+    if (first == last || want <= 0) return;
+    int sp = 0;
+    int f = first, l = last, d = lg_(last - first) * 2;
+    while (true) {
+        while (l - f > 16) {
+            if (d == 0) { heap_select_(A, f, l, l); sort_heap_(A, f, l); break; }
+            --d;
+            const int cut = unguarded_partition_pivot_(A, f, l);
+            if (cut < first + want) { stack[3 * sp] = cut; stack[3 * sp + 1] = l; stack[3 * sp + 2] = d; ++sp; }
+            l = cut;
+        }
+        if (sp == 0) break;
+        --sp;
+        f = uni(stack[3 * sp]); l = uni(stack[3 * sp + 1]); d = uni(stack[3 * sp + 2]);
+    }
+    const int lim = first + want + 16 < last ? first + want + 16 : last;
+    for (int i = first; i < lim; ++i) {
+        const u64 v = A.get(i);
+        int pos = i;
+        for (int dlt = 1; dlt < 16; ++dlt) {
+            const int jb = i - dlt, ja = i + dlt;
+            if (jb >= first && comp(v, A.get(jb))) --pos;               // key_jb < key_i: it ends up behind i
+            if (ja < last && comp(A.get(ja), v)) ++pos;                 // key_ja > key_i: it ends up in front of i
+        }
+        if (pos - first < want) out[pos - first] = (int64_t)(v & 0xffffffffull);
+    }
+}
+
 }  // namespace kvc

@@ -58,6 +58,52 @@ class TopkTap:
         torch.Tensor.topk = self.orig
 
 
+def run_ragged_case(c):
+    """AdaKV / HeadKV (pyramidkv_utils.py:622-878): update_kv(key, query, value) -> flattened K, V [sum_h (cap_h + W), D] and the
+    per-head lengths.  Stored: head_lens, SHA-256 of the flattened K / V, the pooled scores (small cases), and the sorted
+    indices the reference kept per head (captured at its .sort call)."""
+    dtype = DT[c["dtype"]]
+    q, k, v = synth.make_qkv(c["Hq"], c["Hkv"], c["L"], c["D"], dtype, c["seed"], peaky=c.get("peaky", False), expanded=True)
+    kw = dict(window_size=c["W"], kernel_size=c["kernel"], pooling=c["pooling"], max_capacity_prompt=c["cap"], layer_idx=0,
+              num_hidden_layers=1)
+    if c["method"] == "adakv":
+        cl = ref.AdaKVCluster(floor=c["floor"], normalize=c["normalize"], **kw)
+    else:
+        cl = ref.HeadKVCluster(head_capacity=[c["head_capacity"]], **kw)
+    taps = []
+    orig_sort = torch.Tensor.sort
+
+    def sort(t, *a, **kwa):
+        r = orig_sort(t, *a, **kwa)
+        taps.append((t.detach().clone(), r.indices.detach().clone()))
+        return r
+    torch.Tensor.sort = sort
+    try:
+        t0 = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            kf, vf = cl.update_kv(k, q, v)
+        dt = time.time() - t0
+    finally:
+        torch.Tensor.sort = orig_sort
+    meta = dict(c)
+    meta["ref_seconds"] = round(dt, 4)
+    meta["passthrough"] = not taps
+    meta["out_shape"] = list(kf.shape)
+    meta["k_out_sha256"], meta["v_out_sha256"] = sha(kf), sha(vf)
+    out = {"head_lens": cl.head_lens.numpy().astype(np.int32)}
+    if taps:
+        sc, idx = taps[0]
+        meta["scores_sha256"] = sha(sc[0])
+        caps = out["head_lens"] - c["W"]
+        kept = np.full((c["Hq"], int(caps.max())), -1, dtype=np.int64)
+        for h in range(c["Hq"]):
+            kept[h, :caps[h]] = idx[0, h, :caps[h]].numpy()
+        out["kept_indices"] = kept
+        if c["L"] <= 1100:
+            out["scores"] = raw_bits(sc[0])
+    return meta, out
+
+
 def make_cluster(c):
     kw = dict(window_size=c["W"], max_capacity_prompt=c["cap"], kernel_size=c["kernel"], pooling=c["pooling"])
     m = c["method"]
@@ -161,6 +207,16 @@ def cases():
     add("C3_h2o_8k", method="h2o", L=8000, cap=128, Hq=32, Hkv=8, D=128, W=8, seed=0)
     for layer in (0, 28, 31):
         add(f"C5_pyramidkv_32k_layer{layer}", method="pyramidkv", L=32000, cap=2048, layer_idx=layer, seed=0, **big)
+    # ---- AdaKV / HeadKV (ragged per-head budgets; window MEAN scoring) ----
+    for dt in ("bf16", "fp16", "fp32"):
+        add(f"adakv_{dt}_L600", method="adakv", dtype=dt, Hq=8, Hkv=2, L=600, D=128, W=8, cap=72, kernel=7, pooling="maxpool", floor=0.2, normalize=True)
+        add(f"adakv_{dt}_avg_nonorm_L600", method="adakv", dtype=dt, Hq=4, Hkv=4, L=600, D=64, W=32, cap=96, kernel=5, pooling="avgpool", floor=0.5, normalize=False)
+        add(f"headkv_{dt}_L600", method="headkv", dtype=dt, Hq=8, Hkv=2, L=600, D=128, W=8, cap=72, kernel=7, pooling="maxpool",
+            head_capacity=[10, 64, 200, 1, 33, 64, 100, 17])
+    add("adakv_bf16_peaky_L1024", method="adakv", dtype="bf16", Hq=8, Hkv=2, L=1024, D=128, W=8, cap=136, kernel=7, pooling="maxpool", floor=0.2, normalize=True, peaky=True)
+    add("adakv_bf16_passthrough", method="adakv", dtype="bf16", Hq=4, Hkv=2, L=60, D=64, W=8, cap=128, kernel=7, pooling="maxpool", floor=0.2, normalize=True)
+    add("adakv_8k_bf16", method="adakv", dtype="bf16", Hq=32, Hkv=8, L=8000, D=128, W=8, cap=128, kernel=7, pooling="maxpool", floor=0.2, normalize=True, seed=0)
+    add("adakv_8k_bf16_peaky", method="adakv", dtype="bf16", Hq=32, Hkv=8, L=8000, D=128, W=8, cap=128, kernel=7, pooling="maxpool", floor=0.2, normalize=True, seed=1, peaky=True)
     return cs
 
 
@@ -177,7 +233,10 @@ def main():
             continue
         small = c["L"] <= 1100 and c["Hq"] <= 8
         t0 = time.time()
-        meta, arrays = run_case(c, store_scores=small)
+        if c["method"] in ("adakv", "headkv"):
+            meta, arrays = run_ragged_case(c)
+        else:
+            meta, arrays = run_case(c, store_scores=small)
         manifest[c["name"]] = meta
         if arrays:
             np.savez_compressed(os.path.join(OUT, c["name"] + ".npz"), **arrays)

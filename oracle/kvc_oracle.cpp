@@ -285,7 +285,8 @@ struct kvco_params {
     int32_t k;            // number of prefix tokens to keep (already resolved per layer)
     int32_t kernel_size;  // pooling kernel (odd)
     int32_t pooling;      // KVCO_POOL_*
-    int32_t full_rows;    // 0: SnapKV/PyramidKV (last W query rows) ; 1: H2O (all L rows)
+    int32_t full_rows;    // 0: SnapKV/PyramidKV (last W query rows, window SUM) ; 1: H2O (all L rows) ;
+                          // 2: AdaKV/HeadKV (last W rows, window MEAN: calcul_attn_sore, pyramidkv_utils.py:647-672)
     int32_t dot_mode, sum_mode, tie_mode;
     int32_t n_threads;    // OpenMP threads (<=0: runtime default)
     int64_t q_stride_h, q_stride_l;   // q[h][l][d] element strides (d contiguous)
@@ -301,7 +302,7 @@ static int scores_impl(const kvco_params& P, const void* q_, const void* k_,
     const raw* q = (const raw*)q_; const raw* kk = (const raw*)k_;
     const int H = P.n_q_heads, G = H / P.n_kv_heads, W = P.window, D = P.head_dim;
     const int64_t L = P.q_len, n = L - W;
-    const int64_t R = P.full_rows ? L : W;            // query rows scored
+    const int64_t R = P.full_rows == 1 ? L : W;       // query rows scored
     const float sqrt_d = (float)std::sqrt((double)D);
 #if defined(_OPENMP)
     if (P.n_threads > 0) omp_set_num_threads(P.n_threads);
@@ -330,10 +331,13 @@ static int scores_impl(const kvco_params& P, const void* q_, const void* k_,
                              for (int64_t j = 0; j < L; ++j) o[j] = DT::st(p[(size_t)j]); }
             for (int64_t j = 0; j < n; ++j) col[(size_t)j].add(p[(size_t)j]);
         }
-        for (int64_t j = 0; j < n; ++j) s[(size_t)j] = rnd<DT>(col[(size_t)j].result());
+        // .sum(dim=-2): fp32 cascade, rounded once.  .mean(dim=-2) (AdaKV / HeadKV): torch computes reduced-precision means as
+        // cast_fp32 -> sum -> div_(W) -> cast (ReduceOps.cpp mean_out: "for accuracy reasons ..."), one rounding as well
+        for (int64_t j = 0; j < n; ++j)
+            s[(size_t)j] = P.full_rows == 2 ? rnd<DT>(col[(size_t)j].result() / (float)W) : rnd<DT>(col[(size_t)j].result());
         if (wsum_out) { raw* o = (raw*)wsum_out + (int64_t)h * n;
                         for (int64_t j = 0; j < n; ++j) o[j] = DT::st(s[(size_t)j]); }
-        pool_row<DT>(s.data(), n, P.kernel_size, P.full_rows ? KVCO_POOL_NONE : P.pooling, c.data());
+        pool_row<DT>(s.data(), n, P.kernel_size, P.full_rows == 1 ? KVCO_POOL_NONE : P.pooling, c.data());
         raw* so = (raw*)scores_out + (int64_t)h * n;
         for (int64_t j = 0; j < n; ++j) so[j] = DT::st(c[(size_t)j]);
     }
@@ -450,6 +454,101 @@ KVCO_API int64_t kvco_pyramid_k(int64_t cap, int64_t W, int64_t q_len, int64_t l
     if (q_len < (cap - W) * 2) return cap - W;
     return max_num - layer_idx * steps;
 }
+
+// ----------------------------------------------------------------------------------------
+// AdaKV / HeadKV (pyramidkv_utils.py:622-757, :760-878) — per-head budgets over ONE scoring front-end
+// (window MEAN + pooling), a ragged ("flattened") compressed cache [sum_h (cap_h + W), D].
+// ----------------------------------------------------------------------------------------
+// attn_score.sort(dim=-1, descending=True) (:702, :851): torch-CPU sort is libstdc++ std::sort on (value, index) with a
+// value-only comparator (checked against torch in this container: identical indices, ties included).
+template <class DT>
+static void sort_desc_impl(const kvco_params& P, const void* scores_, int64_t* idx_out, void* val_out) {
+    typedef typename DT::raw raw;
+    const int H = P.n_q_heads; const int64_t n = P.q_len - P.window;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int h = 0; h < H; ++h) {
+        const raw* s = (const raw*)scores_ + (int64_t)h * n;
+        std::vector<std::pair<float, int64_t>> a((size_t)n);
+        for (int64_t j = 0; j < n; ++j) a[(size_t)j] = std::make_pair(DT::ld(s[j]), j);
+        std::sort(a.begin(), a.end(), [](const std::pair<float, int64_t>& x, const std::pair<float, int64_t>& y) {
+            return ((std::isnan(x.first) && !std::isnan(y.first)) || (x.first > y.first)); });
+        for (int64_t j = 0; j < n; ++j) {
+            idx_out[(int64_t)h * n + j] = a[(size_t)j].second;
+            if (val_out) ((raw*)val_out)[(int64_t)h * n + j] = DT::st(a[(size_t)j].first);
+        }
+    }
+}
+KVCO_API int kvco_sort_desc(const kvco_params* P, const void* scores, int64_t* idx_out, void* val_out) {
+    if (int e = check(*P)) return e;
+    switch (P->dtype) {
+        case KVCO_BF16: sort_desc_impl<DtBf16>(*P, scores, idx_out, val_out); break;
+        case KVCO_FP16: sort_desc_impl<DtFp16>(*P, scores, idx_out, val_out); break;
+        default:        sort_desc_impl<DtFp32>(*P, scores, idx_out, val_out); break;
+    }
+    return 0;
+}
+// AdaKV's per-head capacities (:701-717) from the SORTED scores [H][n] (dtype):
+//   ratio = sorted[:, :base].sum(-1) / sorted.sum(-1)  (normalize)  ->  adaptive = sorted * ratio  (each op rounds to dtype)
+//   topk(H * base) over the flattened [H * n] values -> count per head -> round(count * (1 - floor) + floor_capacity)
+// Sums: fp32 accumulation in sorted order, rounded once to dtype — torch's vectorised inner sum adds in another order;
+// the difference is ~1e-7 relative before a rounding to 8 / 11 mantissa bits (pinned by the fixtures).
+template <class DT>
+static void adakv_caps_impl(const kvco_params& P, const void* sorted_, int64_t base, double floor_ratio, int normalize, int32_t* caps) {
+    typedef typename DT::raw raw;
+    const int H = P.n_q_heads; const int64_t n = P.q_len - P.window;
+    const raw* sv = (const raw*)sorted_;
+    std::vector<float> flat((size_t)H * n);
+    for (int h = 0; h < H; ++h) {
+        float ratio = 1.0f;
+        if (normalize) {
+            float a = 0.0f, b = 0.0f;
+            for (int64_t j = 0; j < n; ++j) { const float v = DT::ld(sv[(int64_t)h * n + j]); b += v; if (j < base) a += v; }
+            ratio = rnd<DT>(rnd<DT>(a) / rnd<DT>(b));
+        }
+        for (int64_t j = 0; j < n; ++j) {
+            const float v = DT::ld(sv[(int64_t)h * n + j]);
+            flat[(size_t)h * n + j] = normalize ? rnd<DT>(v * ratio) : v;
+        }
+    }
+    const int64_t k = (int64_t)H * base;
+    std::vector<int64_t> idx((size_t)k);
+    std::vector<float> val((size_t)k);
+    topk_row(flat.data(), (int64_t)H * n, k, KVCO_TIES_TORCH, idx.data(), val.data());
+    std::vector<int64_t> cnt((size_t)H, 0);
+    for (int64_t t = 0; t < k; ++t) cnt[(size_t)(idx[(size_t)t] / n)]++;
+    const int64_t floor_capacity = (int64_t)((double)base * floor_ratio);                 // int(base_capacity * floor_ratio)  (:632)
+    const float mix = (float)(1.0 - floor_ratio);                                          // python double -> the fp32 op's scalar
+    for (int h = 0; h < H; ++h)                                                            // torch.round: half to even
+        caps[h] = (int32_t)std::nearbyintf((float)cnt[(size_t)h] * mix + (float)floor_capacity);
+}
+KVCO_API int kvco_adakv_caps(const kvco_params* P, const void* sorted_vals, int64_t base, double floor_ratio, int normalize, int32_t* caps) {
+    if (int e = check(*P)) return e;
+    switch (P->dtype) {
+        case KVCO_BF16: adakv_caps_impl<DtBf16>(*P, sorted_vals, base, floor_ratio, normalize, caps); break;
+        case KVCO_FP16: adakv_caps_impl<DtFp16>(*P, sorted_vals, base, floor_ratio, normalize, caps); break;
+        default:        adakv_caps_impl<DtFp32>(*P, sorted_vals, base, floor_ratio, normalize, caps); break;
+    }
+    return 0;
+}
+// The flattened cache of one tensor (:721-757): for every head, its first caps[h] sorted indices' rows, then the window rows.
+KVCO_API int kvco_ragged_gather(const kvco_params* P, const void* src_, int64_t stride_h, int64_t stride_l, const int64_t* sorted_idx,
+                                const int32_t* caps, void* out_) {
+    if (int e = check(*P)) return e;
+    const size_t esize = P->dtype == KVCO_FP32 ? 4 : 2;
+    const int H = P->n_q_heads, G = H / P->n_kv_heads, W = P->window, D = P->head_dim;
+    const int64_t L = P->q_len, n = L - W;
+    const char* src = (const char*)src_; char* out = (char*)out_;
+    int64_t row = 0;
+    for (int h = 0; h < H; ++h) {
+        const char* sh = src + (int64_t)(h / G) * stride_h * esize;
+        for (int64_t t = 0; t < caps[h]; ++t, ++row)
+            std::memcpy(out + row * D * esize, sh + sorted_idx[(int64_t)h * n + t] * stride_l * esize, (size_t)D * esize);
+        for (int w = 0; w < W; ++w, ++row)
+            std::memcpy(out + row * D * esize, sh + (L - W + w) * stride_l * esize, (size_t)D * esize);
+    }
+    return 0;
+}
+
 // Scalar probes used by tests to pin the helper arithmetic.
 KVCO_API float kvco_exp_u20(float x) { return exp_u20(x); }
 KVCO_API float kvco_sum(const float* x, int64_t n, int sum_mode) {

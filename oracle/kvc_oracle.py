@@ -56,6 +56,9 @@ def lib():
         L.kvco_gather.argtypes = [pp, vp, ctypes.c_int64, ctypes.c_int64, i64p, vp]
         L.kvco_compress.argtypes = [pp, vp, vp, vp, vp, vp, i64p, vp]
         L.kvco_streaming.argtypes = [pp, vp, vp, vp, vp, i64p]
+        L.kvco_sort_desc.argtypes = [pp, vp, i64p, vp]
+        L.kvco_adakv_caps.argtypes = [pp, vp, ctypes.c_int64, ctypes.c_double, ctypes.c_int, vp]
+        L.kvco_ragged_gather.argtypes = [pp, vp, ctypes.c_int64, ctypes.c_int64, i64p, vp, vp]
         L.kvco_pyramid_k.argtypes = [ctypes.c_int64] * 6
         L.kvco_pyramid_k.restype = ctypes.c_int64
         L.kvco_exp_u20.argtypes = [ctypes.c_float]
@@ -106,10 +109,11 @@ def _rc(code, what):
 
 
 def scores(q, k, window, kernel_size=5, pooling="avgpool", full_rows=False, want_intermediates=False, **modes):
-    """A1-A5 (A10 with full_rows).  Returns pooled scores [Hq, n] (+ logits, probs, wsum)."""
+    """A1-A5 (A10 with full_rows = True / 1; full_rows = 2: window MEAN, AdaKV / HeadKV).  Returns pooled scores [Hq, n]
+    (+ logits, probs, wsum)."""
     p = make_params(q, k, None, window, 0, kernel_size, pooling, full_rows, **modes)
     H, L = q.shape[1], q.shape[2]
-    n, R = L - window, (L if full_rows else window)
+    n, R = L - window, (L if int(full_rows) == 1 else window)
     out = torch.empty(H, n, dtype=q.dtype)
     lg = pr = ws = None
     if want_intermediates:
@@ -174,6 +178,32 @@ def streaming(k, v, window, n_keep, n_q_heads):
     idx = torch.empty(n_q_heads, n_keep, dtype=torch.int64)
     _rc(lib().kvco_streaming(ctypes.byref(p), _ptr(k), _ptr(v), _ptr(k_out), _ptr(v_out), _ptr(idx)), "streaming")
     return k_out, v_out, idx
+
+
+def ragged(q, k, v, window, max_capacity_prompt, kernel_size=7, pooling="maxpool", floor=0.2, normalize=True, head_capacity=None,
+           n_threads=0):
+    """AdaKV (head_capacity None: budgets from the scores, pyramidkv_utils.py:674-757) or HeadKV (head_capacity: per-head list,
+    :813-878).  Returns (k_flat [sum_h (cap_h + W), D], v_flat, head_lens int32 [H], caps int32 [H], sorted idx int64 [H, n],
+    pooled scores [H, n])."""
+    sc = scores(q, k, window, kernel_size, pooling, full_rows=2, n_threads=n_threads)
+    H, n = sc.shape
+    p = make_params(q, k, v, window, 0, kernel_size, pooling, n_threads=n_threads)
+    idx = torch.empty(H, n, dtype=torch.int64)
+    val = torch.empty(H, n, dtype=sc.dtype)
+    _rc(lib().kvco_sort_desc(ctypes.byref(p), _ptr(sc), _ptr(idx), _ptr(val)), "sort_desc")
+    base = max_capacity_prompt - window
+    caps = torch.empty(H, dtype=torch.int32)
+    if head_capacity is None:
+        _rc(lib().kvco_adakv_caps(ctypes.byref(p), _ptr(val), base, float(floor), int(bool(normalize)), _ptr(caps)), "adakv_caps")
+    else:
+        caps.copy_(torch.as_tensor(head_capacity, dtype=torch.int32))
+    lens = caps + window
+    rows = int(lens.sum())
+    kf = torch.empty(rows, k.shape[3], dtype=k.dtype)
+    vf = torch.empty_like(kf)
+    _rc(lib().kvco_ragged_gather(ctypes.byref(p), _ptr(k), k.stride(1), k.stride(2), _ptr(idx), _ptr(caps), _ptr(kf)), "ragged_gather")
+    _rc(lib().kvco_ragged_gather(ctypes.byref(p), _ptr(v), v.stride(1), v.stride(2), _ptr(idx), _ptr(caps), _ptr(vf)), "ragged_gather")
+    return kf, vf, lens.to(torch.int32), caps, idx, sc
 
 
 def pyramid_k(cap, window, q_len, layer_idx, n_layers, beta=20):

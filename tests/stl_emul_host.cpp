@@ -89,6 +89,30 @@ int main(int argc, char** argv) {
             if (a[i] != b[i]) { printf("MISMATCH trial %d n=%d k=%d at %d: real %ld emul %ld\n", t, n, k, i, (long)a[i], (long)b[i]); return 1; }
         checked += k;
     }
+    // AdaKV / HeadKV: a prefix of the FULL std::sort (torch-CPU sort, descending) through sort_prefix_
+    for (int t = 0; t < trials; ++t) {
+        const int n = (t % 4 == 0) ? 7992 : 17 + (int)(rng() % 9000);
+        int want = (t % 5 == 0) ? n : 1 + (int)(rng() % (n < 600 ? n : 600));
+        if (t % 7 == 0) want = 1 + (int)(rng() % n);
+        const int distinct = (t % 3 == 0) ? 3 : (t % 3 == 1 ? 260 : 100000);
+        std::vector<float> v(n);
+        for (int i = 0; i < n; ++i) v[i] = (float)(rng() % distinct) / (float)distinct;
+        if (t % 5 == 1) for (int i = 0; i + 7 < n; i += 7) { float m = v[i]; for (int j = 1; j < 7; ++j) m = std::max(m, v[i + j]); for (int j = 0; j < 7; ++j) v[i + j] = m; }
+        if (t % 11 == 0) std::fill(v.begin(), v.end(), 0.125f);
+        if (t % 13 == 0) std::sort(v.begin(), v.end());
+        std::vector<elem> q(n);
+        for (int i = 0; i < n; ++i) q[i] = elem(v[i], i);
+        std::sort(q.begin(), q.end(), [](const elem& x, const elem& y) { return x.first > y.first; });
+        std::vector<u64> arr(n);
+        for (int i = 0; i < n; ++i) arr[i] = ((u64)key_of(v[i]) << 32) | (uint32_t)i;
+        kvc::Arr A{arr.data()};
+        std::vector<int> stack(3 * 96);
+        std::vector<int64_t> out(want, -1);
+        kvc::sort_prefix_(A, 0, n, want, stack.data(), out.data());
+        for (int i = 0; i < want; ++i)
+            if (out[i] != q[i].second) { printf("SORT-PREFIX MISMATCH trial %d n=%d want=%d at %d: real %ld emul %ld\n", t, n, want, i, (long)q[i].second, (long)out[i]); return 1; }
+        checked += want;
+    }
     printf("OK %d trials, %ld indices identical to libstdc++\n", trials, checked);
     return 0;
 }

@@ -557,7 +557,8 @@ def test_decode_cache_growth_on_gpu(kvc, gpu_device, monkeypatch):
     for a, b in zip(outs[True].scores, outs[False].scores):
         assert torch.equal(a, b)                                           # decode-step logits, bit for bit
     for la, lb in zip(outs[True].past_key_values.layers, outs[False].past_key_values.layers):
-        assert torch.equal(la.keys, lb.keys) and torch.equal(la.values, lb.values) and la.keys.shape[2] == la._stored
+        assert torch.equal(la.keys, lb.keys) and torch.equal(la.values, lb.values)
+        assert la._split and la._tail == 13 and la._ktail.shape[2] >= 13 and la.keys.shape[2] == la._stored + la._tail   # tail grew past RESERVE = 3
 
 
 def test_layers_on_a_second_gpu(kvc, oracle):
@@ -793,3 +794,79 @@ def test_decode_logits_vs_oracle_built_cache(kvc, oracle, gpu_device, method, mo
         assert la._split and not lb._split                               # (a) really took the split form, (b) the expanded one
         assert torch.equal(la._kbuf[:, :, :la._stored], lb._kbuf[:, :, :la._stored])      # same compressed prompt, byte for byte
         assert la.keys.shape == lb.keys.shape and la.get_seq_length() == lb.get_seq_length() == 505
+
+
+RAGGED = lambda m: m["method"] in ("adakv", "headkv") and not m["passthrough"]      # noqa: E731
+
+
+@pytest.mark.parametrize("name", G.names(RAGGED))
+def test_ragged_adakv_headkv_vs_reference(kvc, oracle, gpu_device, name):
+    """N3: AdaKV / HeadKV on the GPU (kvc_ragged_plan + kvc_ragged_compact) against the REFERENCE's golden vectors: per-head
+    lengths (AdaKV budgets from the global top-(H*base); HeadKV's given ones), the indices every head keeps — a prefix of
+    torch-CPU's descending sort, tie order included — and the flattened K / V byte for byte (SHA-256); pooled window-mean
+    scores bit-exact against the oracle.  fp32: lengths within 1 row per head (torch's fp32 softmax exp is opaque)."""
+    m, arr = G.MANIFEST[name], G.arrays(name)
+    q, k, v = G.inputs(m, device=gpu_device, expanded=False)
+    meth = kvc.ADAKV if m["method"] == "adakv" else kvc.HEADKV
+    r = kvc.ragged_compress(meth, q, k, v, m["W"], m["cap"] - m["W"], m["kernel"], m["pooling"], m.get("floor", 0.2),
+                            m.get("normalize", True), m.get("head_capacity"), return_indices=True, return_scores=True)
+    sc_o = oracle.scores(q.cpu(), k.cpu(), m["W"], m["kernel"], m["pooling"], full_rows=2, **G.product_modes(oracle, m))
+    assert torch.equal(G.bits(r["scores"][0]), G.bits(sc_o))                # tolerance: 0 ulp
+    ref_lens = arr["head_lens"].tolist()
+    if m["dtype"] == "fp32":
+        assert max(abs(a - b) for a, b in zip(r["lens"], ref_lens)) <= 1
+        return
+    assert int(r["flag"].sum()) == 0                                        # no cross-head tie at the global threshold here
+    assert r["lens"] == ref_lens
+    kept = torch.from_numpy(arr["kept_indices"])
+    got = r["idx"].cpu()
+    for h, ln in enumerate(ref_lens):
+        c = ln - m["W"]
+        assert torch.equal(got[h, :c], kept[h, :c]), h
+    assert list(r["k_flat"].shape) == m["out_shape"]
+    assert G.sha(r["k_flat"]) == m["k_out_sha256"] and G.sha(r["v_flat"]) == m["v_out_sha256"]
+    if meth == kvc.ADAKV:      # tie_mode canonical: budgets by a threshold search; values equal to the global threshold that span
+        rc = kvc.ragged_compress(meth, q, k, v, m["W"], m["cap"] - m["W"], m["kernel"], m["pooling"], m.get("floor", 0.2),   # several heads
+                                 m.get("normalize", True), tie_mode="canonical")       # are shared out in flattened order and flagged
+        assert sum(rc["lens"]) in range(sum(ref_lens) - m["Hq"], sum(ref_lens) + m["Hq"] + 1)
+        if int(rc["flag"].sum()) == 0:
+            assert rc["lens"] == ref_lens
+    # with spare rows behind every head the segments hold the same bytes
+    r2 = kvc.ragged_compress(meth, q, k, v, m["W"], m["cap"] - m["W"], m["kernel"], m["pooling"], m.get("floor", 0.2),
+                             m.get("normalize", True), m.get("head_capacity"), slack=5)
+    row = 0
+    for h, ln in enumerate(r2["lens"]):
+        o = int(r2["seg_off"][h])
+        assert torch.equal(r2["k_flat"][o:o + ln], r["k_flat"][row:row + ln]) and torch.equal(r2["v_flat"][o:o + ln], r["v_flat"][row:row + ln])
+        row += ln
+
+
+def test_ragged_decode_step_vs_reference_shaped_attention(kvc, gpu_device):
+    """kvc_ragged_decode_step: the step's K/V rows are appended IN PLACE behind every head's segment (the reference re-copies the
+    whole flattened cache per token, cuda_api.cu:12-85) and each head attends over its own segment (flash_attn_varlen_func,
+    llama_model.py:2386) — compared with per-head softmax attention in fp32, two steps in a row."""
+    torch.manual_seed(3)
+    hq, hkv, D, dtype = 8, 2, 128, torch.bfloat16
+    lens = [40, 9, 133, 64, 17, 300, 8, 77]
+    slack = 4
+    offs, row = [], 0
+    for ln in lens:
+        offs.append(row)
+        row += ln + slack
+    kf = torch.randn(row, D, device=gpu_device).to(dtype)
+    vf = torch.randn(row, D, device=gpu_device).to(dtype)
+    seg_off = torch.tensor(offs, dtype=torch.int64, device=gpu_device)
+    seg_len = torch.tensor(lens, dtype=torch.int32, device=gpu_device)
+    ref_k = [kf[o:o + ln].float() for o, ln in zip(offs, lens)]
+    ref_v = [vf[o:o + ln].float() for o, ln in zip(offs, lens)]
+    for step in range(2):
+        q = torch.randn(1, hq, 1, D, device=gpu_device).to(dtype)
+        kn, vn = torch.randn(1, hkv, 1, D, device=gpu_device).to(dtype), torch.randn(1, hkv, 1, D, device=gpu_device).to(dtype)
+        out = kvc.ragged_decode_step(q, kn, vn, kf, vf, seg_off, seg_len, step, D ** -0.5)
+        for h in range(hq):
+            ref_k[h] = torch.cat([ref_k[h], kn[0, h // 4].float()], 0)
+            ref_v[h] = torch.cat([ref_v[h], vn[0, h // 4].float()], 0)
+            o = offs[h] + lens[h] + step
+            assert torch.equal(kf[o], kn[0, h // 4, 0]) and torch.equal(vf[o], vn[0, h // 4, 0])
+            want = torch.softmax(q[0, h].float() @ ref_k[h].T * D ** -0.5, -1) @ ref_v[h]
+            assert float((out[0, 0, h].float() - want[0]).abs().max()) <= 2.0 ** -7 * max(1.0, float(want.abs().max()))
