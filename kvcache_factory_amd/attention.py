@@ -25,7 +25,7 @@ import torch
 from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
 
 from . import pyramidkv_utils as pu
-from .cache import CompressedDynamicLayer
+from .cache import CompressedDynamicLayer, RaggedDynamicLayer
 
 _INIT = {
     "pyramidkv": lambda self: pu.init_pyramidkv(self, num_hidden_layers=self.config.num_hidden_layers),
@@ -150,6 +150,53 @@ def make_forward(method, apply_rotary_pos_emb, eager_attention_forward, repeat_k
         attn_output = attn_output.reshape(*input_shape, -1).contiguous()
         attn_output = self.o_proj(attn_output)
         return attn_output, attn_weights
+
+    forward.__name__ = f"kvc_attn_forward_{method}"
+    forward.kvc_method = method
+    return forward
+
+
+def make_ragged_forward(method, apply_rotary_pos_emb, eager_attention_forward, repeat_kv):
+    """AdaKV / HeadKV forward — counterpart of llama_flash_attn2_forward_AdaKV / _HeadKV (llama_model.py:2255-2398, :2400-2543):
+    prefill: `K_flat, V_flat = self.kv_cluster.update_kv(K, Q, V)` (:2322) goes into the flattened cache and this step's
+    attention runs on the uncompressed K/V; decode: the reference calls update_flatten_view + flash_attn_varlen_func over the
+    flattened cache (:2363-2390) — here one kvc_ragged_decode_step.  bsz = 1 like the reference (:719 `assert bsz == 1`)."""
+    init = pu.init_adakv if method == "adakv" else pu.init_headkv
+
+    def forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None, **kwargs):
+        init(self)
+        input_shape = hidden_states.shape[:-1]
+        hidden_shape = (*input_shape, -1, self.head_dim)
+        query_states = self.q_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+        key_states = self.k_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+        value_states = self.v_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+        cos, sin = position_embeddings
+        query_states, key_states = apply_rotary_pos_emb(query_states, key_states, cos, sin)
+        if past_key_values is not None:
+            layers = past_key_values.layers
+            while len(layers) <= self.layer_idx:
+                layers.append(RaggedDynamicLayer())
+            if not isinstance(layers[self.layer_idx], RaggedDynamicLayer):
+                if layers[self.layer_idx].get_seq_length() != 0:
+                    raise RuntimeError("kvcache_factory_amd: start generation from an empty cache")
+                layers[self.layer_idx] = RaggedDynamicLayer()
+            layer = layers[self.layer_idx]
+            if layer.get_seq_length() == 0:                                  # prefill (:2322)
+                self.kv_cluster.update_kv(key_states, query_states, value_states, slack=pu.RAGGED_SLACK)
+                r = self.kv_cluster.ragged
+                if r is None:                                                # "not compress" (:696): every head keeps all rows
+                    raise NotImplementedError("AdaKV / HeadKV with max_capacity_prompt above the prompt length: nothing to compress")
+                layer.prefill(r, key_states.shape[-2])
+            else:                                                            # decode (:2363-2390)
+                attn_output = layer.decode_attend(query_states, key_states, value_states, self.scaling)
+                return self.o_proj(attn_output.reshape(*input_shape, -1)), None
+        attention_interface: Callable = ALL_ATTENTION_FUNCTIONS.get_interface(
+            self.config._attn_implementation, eager_attention_forward)
+        attn_output, attn_weights = attention_interface(
+            self, query_states, key_states, value_states, attention_mask,
+            dropout=0.0 if not self.training else self.attention_dropout, scaling=self.scaling, **kwargs)
+        attn_output = attn_output.reshape(*input_shape, -1).contiguous()
+        return self.o_proj(attn_output), attn_weights
 
     forward.__name__ = f"kvc_attn_forward_{method}"
     forward.kvc_method = method

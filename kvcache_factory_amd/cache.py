@@ -157,3 +157,68 @@ class CompressedDynamicLayer(DynamicLayer):
 
     def crop(self, *a, **kw):
         raise NotImplementedError("a compressed cache cannot be cropped by position")
+
+
+class RaggedDynamicLayer(DynamicLayer):
+    """The flattened cache of AdaKV / HeadKV for one layer — counterpart of the reference's DynamicCacheSplitHeadFlatten
+    (pyramidkv_utils.py:28-102), whose every decode step allocates a new tensor and re-copies the whole cache with one row
+    inserted per head (update_flatten_view, csrc/csrc/cuda_api.cu:12-85).  Here every head's segment has spare rows behind it
+    and kvc_ragged_decode_step appends in place; when a segment fills up, the cache is re-laid out once with twice the slack."""
+
+    def __init__(self):
+        super().__init__()
+        self.true_length = 0
+        self.k_flat = self.v_flat = self.seg_off = self.seg_len = None
+        self.lens, self.slack, self.appended = [], 0, 0
+
+    keys = property(lambda self: self.k_flat, lambda self, v: None)
+    values = property(lambda self: self.v_flat, lambda self, v: None)
+
+    def prefill(self, ragged, true_length):
+        if not self.is_initialized:
+            self.lazy_initialization(ragged["k_flat"], ragged["v_flat"])
+        self.k_flat, self.v_flat = ragged["k_flat"], ragged["v_flat"]
+        self.seg_off, self.seg_len = ragged["seg_off"], ragged["seg_len"]
+        self.lens, self.slack, self.appended = list(ragged["lens"]), ragged["slack"], 0
+        self.true_length = int(true_length)
+
+    def _regrow(self, need):
+        slack = max(2 * self.slack, need)
+        offs, row = [], 0
+        for ln in self.lens:
+            offs.append(row)
+            row += ln + slack
+        new_off = torch.tensor(offs, dtype=torch.int64, device=self.k_flat.device)
+        kf = torch.empty(row, self.k_flat.shape[1], dtype=self.k_flat.dtype, device=self.k_flat.device)
+        vf = torch.empty_like(kf)
+        old = self.seg_off.tolist()
+        for h, ln in enumerate(self.lens):
+            m = ln + self.appended
+            kf[offs[h]:offs[h] + m].copy_(self.k_flat[old[h]:old[h] + m])
+            vf[offs[h]:offs[h] + m].copy_(self.v_flat[old[h]:old[h] + m])
+        self.k_flat, self.v_flat, self.seg_off, self.slack = kf, vf, new_off, slack
+
+    def decode_attend(self, query_states, key_states, value_states, scaling):
+        from . import _kvc
+        t = key_states.shape[-2]
+        if self.appended + t > self.slack:
+            self._regrow(self.appended + t)
+        out = _kvc.ragged_decode_step(query_states, key_states, value_states, self.k_flat, self.v_flat, self.seg_off, self.seg_len,
+                                      self.appended, scaling)
+        self.appended += t
+        self.true_length += t
+        return out
+
+    def segments(self):
+        """Per head: (keys, values) views of its rows (prefill + appended) — for tests and tools."""
+        offs = self.seg_off.tolist()
+        return [(self.k_flat[o:o + ln + self.appended], self.v_flat[o:o + ln + self.appended]) for o, ln in zip(offs, self.lens)]
+
+    def get_seq_length(self):
+        return self.true_length
+
+    def get_mask_sizes(self, query_length):
+        return max(self.lens or [0]) + self.appended + query_length, 0
+
+    def crop(self, *a, **kw):
+        raise NotImplementedError("a compressed cache cannot be cropped by position")

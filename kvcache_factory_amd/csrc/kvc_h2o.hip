@@ -567,10 +567,14 @@ __global__ __launch_bounds__(FAST_THREADS, 2) void h2o_fast_stats_kernel(const H
         if (t + 1 < n_t) gload(t + 1);
         const char* const buf = smem + (t & 1) * (32 * ROWP);
         f32x16 acc[2];
-        acc[0] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        acc[1] = acc[0];
+        {
+            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // C = 0 folds into the first MFMA
+            const uint4 ak = *reinterpret_cast<const uint4*>(buf + j * ROWP + kh * 16);
+            acc[0] = mfma_pk16<DT>(ak, bq[0][0], zero);
+            acc[1] = mfma_pk16<DT>(ak, bq[1][0], zero);
+        }
 #pragma unroll
-        for (int s_ = 0; s_ < NS; ++s_) {
+        for (int s_ = 1; s_ < NS; ++s_) {
             const uint4 ak = *reinterpret_cast<const uint4*>(buf + j * ROWP + (2 * s_ + kh) * 16);   // A operand: key row j of the tile
             acc[0] = mfma_pk16<DT>(ak, bq[0][s_], acc[0]);
             acc[1] = mfma_pk16<DT>(ak, bq[1][s_], acc[1]);
@@ -594,10 +598,10 @@ __global__ __launch_bounds__(FAST_THREADS, 2) void h2o_fast_stats_kernel(const H
                     x[e] = (key >= L || masked) ? kNeg : x[e];
                 }
             }
-            float mt = x[0];
+            float mt = __builtin_fmaxf(x[0], x[1]);                        // (no NaN can reach here from finite inputs; v_max_f32)
 #pragma unroll
-            for (int e = 1; e < 16; ++e) mt = x[e] > mt ? x[e] : mt;
-            const float mn = mt > mrun[rt] ? mt : mrun[rt];
+            for (int e = 2; e < 16; ++e) mt = __builtin_fmaxf(mt, x[e]);
+            const float mn = __builtin_fmaxf(mt, mrun[rt]);
             const float f = __builtin_amdgcn_exp2f((mrun[rt] - mn) * kLog2e);
             const float c = -mn * kLog2e;
             f32x2 part = {0.0f, 0.0f};
@@ -678,13 +682,17 @@ __global__ __launch_bounds__(FAST_THREADS, 2) void h2o_fast_colsum_kernel(const 
         if (t + 1 < n_t) gload(t + 1);
         const char* const buf = smem + (t & 1) * BUF;
         f32x16 acc[2];
-        acc[0] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        acc[1] = acc[0];
+        {
+            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const uint4 aq = *reinterpret_cast<const uint4*>(buf + j * ROWP + kh * 16);
+            acc[0] = mfma_pk16<DT>(aq, bk[0][0], zero);                     // (a dead column tile is computed and ignored: no branch
+            acc[1] = mfma_pk16<DT>(aq, bk[1][0], zero);                     //  inside the MFMA chain)
+        }
 #pragma unroll
-        for (int s_ = 0; s_ < NS; ++s_) {
+        for (int s_ = 1; s_ < NS; ++s_) {
             const uint4 aq = *reinterpret_cast<const uint4*>(buf + j * ROWP + (2 * s_ + kh) * 16);   // A operand: query row j of the tile
-            if (live[0]) acc[0] = mfma_pk16<DT>(aq, bk[0][s_], acc[0]);
-            if (live[1]) acc[1] = mfma_pk16<DT>(aq, bk[1][s_], acc[1]);
+            acc[0] = mfma_pk16<DT>(aq, bk[0][s_], acc[0]);
+            acc[1] = mfma_pk16<DT>(aq, bk[1][s_], acc[1]);
         }
         // this lane's sixteen rows of the tile: 8 g + 4 kh + e
         float mr[16], rr[16];

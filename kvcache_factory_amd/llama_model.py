@@ -3,7 +3,7 @@ sdpa :208/:1305/:1663/:2020 and flash-attn copies of one template).  transformer
 whose backend is picked at call time, so one forward per method replaces the reference's three."""
 from transformers.models.llama import modeling_llama as _ml
 
-from .attention import make_forward
+from .attention import make_forward, make_ragged_forward
 
 
 def _mk(method):
@@ -14,5 +14,9 @@ llama_attn_forward_PyramidKV = llama_sdpa_attn_forward_PyramidKV = _mk("pyramidk
 llama_attn_forward_SnapKV = llama_sdpa_attn_forward_SnapKV = _mk("snapkv")
 llama_attn_forward_H2O = llama_sdpa_attn_forward_H2O = _mk("h2o")
 llama_attn_forward_StreamingLLM = llama_sdpa_attn_forward_StreamingLLM = _mk("streamingllm")
+# AdaKV / HeadKV: the reference only has flash-attn forwards for them (llama_model.py:2255, :2400)
+llama_flash_attn2_forward_AdaKV = make_ragged_forward("adakv", _ml.apply_rotary_pos_emb, _ml.eager_attention_forward, _ml.repeat_kv)
+llama_flash_attn2_forward_HeadKV = make_ragged_forward("headkv", _ml.apply_rotary_pos_emb, _ml.eager_attention_forward, _ml.repeat_kv)
 FORWARDS = {"pyramidkv": llama_attn_forward_PyramidKV, "snapkv": llama_attn_forward_SnapKV,
-            "h2o": llama_attn_forward_H2O, "streamingllm": llama_attn_forward_StreamingLLM}
+            "h2o": llama_attn_forward_H2O, "streamingllm": llama_attn_forward_StreamingLLM,
+            "adakv": llama_flash_attn2_forward_AdaKV, "headkv": llama_flash_attn2_forward_HeadKV}

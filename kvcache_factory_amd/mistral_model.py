@@ -2,7 +2,7 @@
 Llama; the only difference in transformers 5.x is the `sliding_window` kwarg handed to the attention function."""
 from transformers.models.mistral import modeling_mistral as _mm
 
-from .attention import make_forward
+from .attention import make_forward, make_ragged_forward
 
 
 def _mk(method):
@@ -14,5 +14,8 @@ mistral_attn_forward_PyramidKV = mistral_sdpa_attn_forward_PyramidKV = _mk("pyra
 mistral_attn_forward_SnapKV = mistral_sdpa_attn_forward_SnapKV = _mk("snapkv")
 mistral_attn_forward_H2O = mistral_sdpa_attn_forward_H2O = _mk("h2o")
 mistral_attn_forward_StreamingLLM = mistral_sdpa_attn_forward_StreamingLLM = _mk("streamingllm")
+mistral_flash_attn2_forward_AdaKV = make_ragged_forward("adakv", _mm.apply_rotary_pos_emb, _mm.eager_attention_forward, _mm.repeat_kv)
+mistral_flash_attn2_forward_HeadKV = make_ragged_forward("headkv", _mm.apply_rotary_pos_emb, _mm.eager_attention_forward, _mm.repeat_kv)
 FORWARDS = {"pyramidkv": mistral_attn_forward_PyramidKV, "snapkv": mistral_attn_forward_SnapKV,
-            "h2o": mistral_attn_forward_H2O, "streamingllm": mistral_attn_forward_StreamingLLM}
+            "h2o": mistral_attn_forward_H2O, "streamingllm": mistral_attn_forward_StreamingLLM,
+            "adakv": mistral_flash_attn2_forward_AdaKV, "headkv": mistral_flash_attn2_forward_HeadKV}

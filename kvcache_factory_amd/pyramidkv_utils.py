@@ -33,6 +33,7 @@ GROUP_LAYERS = int(os.environ.get("KVC_GROUP_LAYERS", "8"))      # ... of this m
 DECODE_KERNEL = os.environ.get("KVC_DECODE_KERNEL", "1") == "1"  # decode steps by kvc_decode_step over the split cache (N1)
 OVERLAP = os.environ.get("KVC_OVERLAP", "1") == "1"              # grouped flushes run on a side stream beside the model's prefill
 SPARE_ROWS = 256                                         # decode rows per head reserved behind the compressed prompt
+RAGGED_SLACK = 256                                       # AdaKV / HeadKV: spare rows behind every head of the flattened cache
 
 
 def _say(msg):
@@ -230,6 +231,86 @@ class StreamingLLMKVCluster(_KVCluster):
     _name, _method = "StreamingLLM", _kvc.STREAMINGLLM
 
 
+class _RaggedCluster:
+    """AdaKV / HeadKV (pyramidkv_utils.py:622-878): `update_kv(key_states, query_states, value_states)` returns the FLATTENED
+    compressed cache — `[sum_h (capacity_h + W), D]` keys and values, head after head — and leaves the reference's varlen
+    metadata on the object: head_lens, cu_headlens, cu_klen, klen_sum, max_seqlen_k, layer_qlens, qlen_sum, cu_qlen,
+    cu_offset, cu_head_offset (:684-699).  K/V may carry H_q heads (the reference) or the model's H_kv heads.
+    `ragged` keeps the library's own handles (segment offsets / lengths on the device) for the in-place decode step."""
+
+    _method = None
+
+    def __init__(self, window_size=32, kernel_size=7, pooling='maxpool', max_capacity_prompt=None, layer_idx=None,
+                 num_hidden_layers=None):
+        self.window_size, self.kernel_size, self.pooling = window_size, kernel_size, pooling
+        self.base_capacity = max_capacity_prompt - window_size
+        self.num_hidden_layers, self.layer_idx = num_hidden_layers, layer_idx
+        self.head_lens, self.max_seqlen_k, self.klen_sum, self.cu_klen = None, 0, 0, 0
+        self.cu_offset = self.cu_headlens = None
+        self.ragged = None
+
+    def _init_metadata(self, num_heads, k_lens, device):                       # :684-699
+        i32 = dict(dtype=torch.int32, device=device)
+        self.head_lens = torch.tensor(k_lens, **i32)
+        self.klen_sum, self.max_seqlen_k = int(sum(k_lens)), int(max(k_lens))
+        self.cu_headlens = torch.cumsum(self.head_lens, dim=0, dtype=torch.int32)
+        self.cu_klen = torch.cat([self.cu_headlens - self.head_lens, torch.tensor([self.klen_sum], **i32)], dim=0)
+        self.layer_qlens = torch.ones(num_heads, **i32)
+        self.qlen_sum = num_heads
+        self.cu_qlen = torch.cat([torch.cumsum(self.layer_qlens, dim=0, dtype=torch.int32) - self.layer_qlens,
+                                  torch.tensor([self.qlen_sum], **i32)], dim=0)
+        self.cu_offset = torch.arange(0, num_heads + 1, **i32)
+        self.cu_head_offset = torch.arange(1, num_heads + 1, **i32)
+
+    def _capacities(self):
+        return None
+
+    def update_kv(self, key_states, query_states, value_states, slack=0):
+        bsz, num_heads, q_len, head_dim = query_states.shape
+        assert bsz == 1                                                        # :719
+        if self.pooling not in ("avgpool", "maxpool"):
+            raise ValueError('Pooling method not supported')                   # :671
+        if self.base_capacity > q_len - self.window_size:                      # :696 "not compress"
+            g = num_heads // key_states.shape[1]
+            k = key_states.repeat_interleave(g, 1) if g > 1 else key_states
+            v = value_states.repeat_interleave(g, 1) if g > 1 else value_states
+            self._init_metadata(num_heads, [q_len] * num_heads, key_states.device)
+            self.ragged = None
+            return k.reshape(-1, head_dim), v.reshape(-1, head_dim)
+        r = _kvc.ragged_compress(self._method, query_states, key_states, value_states, self.window_size, self.base_capacity,
+                                 self.kernel_size, self.pooling, getattr(self, "floor_ratio", 0.0), getattr(self, "normalize", False),
+                                 self._capacities(), slack=slack, tie_mode=TIE_MODE)
+        self._init_metadata(num_heads, r["lens"], key_states.device)
+        self.ragged = r
+        return r["k_flat"], r["v_flat"]
+
+
+class AdaKVCluster(_RaggedCluster):
+    """pyramidkv_utils.py:622-757: budgets from a global top-(H * base_capacity) over the heads' normalised scores, mixed with
+    a floor: capacity_h = round(count_h * (1 - floor) + int(base_capacity * floor))."""
+    _method = _kvc.ADAKV
+
+    def __init__(self, window_size=32, kernel_size=7, pooling='maxpool', max_capacity_prompt=None, floor=None, normalize=None,
+                 layer_idx=None, num_hidden_layers=None):
+        super().__init__(window_size, kernel_size, pooling, max_capacity_prompt, layer_idx, num_hidden_layers)
+        self.floor_ratio, self.normalize = floor, normalize
+        self.floor_capacity = int(self.base_capacity * self.floor_ratio)
+        self.adaptive_capacity = self.base_capacity - self.floor_capacity
+
+
+class HeadKVCluster(_RaggedCluster):
+    """pyramidkv_utils.py:760-878: capacities given per layer and head (`head_capacity[layer_idx][head]`)."""
+    _method = _kvc.HEADKV
+
+    def __init__(self, window_size=32, kernel_size=7, pooling='maxpool', max_capacity_prompt=None, layer_idx=None,
+                 num_hidden_layers=None, head_capacity=None):
+        super().__init__(window_size, kernel_size, pooling, max_capacity_prompt, layer_idx, num_hidden_layers)
+        self.head_adaptive_capacity = head_capacity
+
+    def _capacities(self):
+        return [int(c) for c in self.head_adaptive_capacity[self.layer_idx]]
+
+
 # ---- init_* factories (pyramidkv_utils.py:880-1031): default-fill self.config on first use, then rebuild
 # ---- self.kv_cluster on EVERY forward so config edits between prompts take effect (clusters are stateless).
 _DEFAULTS = (("window_size", 32), ("kernel_size", 5), ("pooling", "avgpool"), ("merge", None))
@@ -263,3 +344,31 @@ def init_H2O(self):
 def init_StreamingLLM(self):
     """pyramidkv_utils.py:1011-1031 (default cap 2048)."""
     _init(self, StreamingLLMKVCluster, 2048)
+
+
+def init_adakv(self):
+    """pyramidkv_utils.py:1033-1060.  (The reference fills `config.floor_ratio` but reads `config.floor`, :1043 / :1057: either
+    name is honoured here.)  Built once per attention module, like the reference."""
+    if not hasattr(self, "kv_cluster"):
+        for name, val in (("window_size", 32), ("max_capacity_prompt", 2048), ("kernel_size", 5), ("pooling", "maxpool"),
+                          ("floor_ratio", 0.2), ("normalize", True)):
+            if not hasattr(self.config, name):
+                setattr(self.config, name, val)
+        c = self.config
+        self.kv_cluster = AdaKVCluster(num_hidden_layers=c.num_hidden_layers, layer_idx=self.layer_idx, window_size=c.window_size,
+                                       max_capacity_prompt=c.max_capacity_prompt, kernel_size=c.kernel_size, pooling=c.pooling,
+                                       floor=getattr(c, "floor", c.floor_ratio), normalize=c.normalize)
+
+
+def init_headkv(self):
+    """pyramidkv_utils.py:1062-1084."""
+    if not hasattr(self, "kv_cluster"):
+        for name, val in (("window_size", 32), ("max_capacity_prompt", 2048), ("kernel_size", 5), ("pooling", "maxpool")):
+            if not hasattr(self.config, name):
+                setattr(self.config, name, val)
+        if not hasattr(self.config, "head_capacity"):
+            raise ValueError("Must have head_capacity")                           # :1073
+        c = self.config
+        self.kv_cluster = HeadKVCluster(num_hidden_layers=c.num_hidden_layers, layer_idx=self.layer_idx, window_size=c.window_size,
+                                        max_capacity_prompt=c.max_capacity_prompt, kernel_size=c.kernel_size, pooling=c.pooling,
+                                        head_capacity=c.head_capacity)

@@ -870,3 +870,61 @@ def test_ragged_decode_step_vs_reference_shaped_attention(kvc, gpu_device):
             assert torch.equal(kf[o], kn[0, h // 4, 0]) and torch.equal(vf[o], vn[0, h // 4, 0])
             want = torch.softmax(q[0, h].float() @ ref_k[h].T * D ** -0.5, -1) @ ref_v[h]
             assert float((out[0, 0, h].float() - want[0]).abs().max()) <= 2.0 ** -7 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("method", ["adakv", "headkv"])
+def test_ragged_clusters_and_patched_model(kvc, oracle, gpu_device, method):
+    """N3 host side: AdaKVCluster / HeadKVCluster.update_kv(key, query, value) returns the flattened cache and leaves the
+    reference's varlen metadata (head_lens, cu_klen, klen_sum, max_seqlen_k) — equal to the oracle's restatement of
+    pyramidkv_utils.py:674-757 / :813-878 on the tensors the cluster saw; replace_llama(method) generates with the in-place
+    ragged decode step, and its decode logits equal (bf16 rounding) a reference-shaped run: per-head attention in torch over
+    the oracle-built segments."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from kvcache_factory_amd import monkeypatch as mp, pyramidkv_utils as pu
+    cfg = LlamaConfig(hidden_size=1024, intermediate_size=256, num_hidden_layers=2, num_attention_heads=8,
+                      num_key_value_heads=2, head_dim=128, vocab_size=256, max_position_embeddings=4096, attn_implementation="sdpa")
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(cfg).to(torch.bfloat16).to(gpu_device).eval()
+    ids = torch.randint(0, 256, (1, 400), generator=torch.Generator().manual_seed(5)).to(gpu_device)
+    head_cap = [[10, 64, 100, 1, 33, 64, 80, 17], [64, 5, 50, 120, 20, 64, 9, 40]]
+    klass = pu.AdaKVCluster if method == "adakv" else pu.HeadKVCluster
+    seen, orig = [], klass.update_kv
+
+    def spy(self, k, q, v, slack=0):
+        r = orig(self, k, q, v, slack)
+        seen.append((self, k.clone(), q.clone(), v.clone(), [int(x) for x in self.head_lens.tolist()], self.klen_sum, self.max_seqlen_k,
+                     self.cu_klen.tolist()))
+        return r
+    try:
+        mp.replace_llama(method)
+        for layer in model.model.layers:
+            for name, val in (("window_size", 8), ("max_capacity_prompt", 72), ("kernel_size", 7), ("pooling", "maxpool"),
+                              ("floor_ratio", 0.2), ("normalize", True), ("head_capacity", head_cap)):
+                setattr(layer.self_attn.config, name, val)
+            if hasattr(layer.self_attn, "kv_cluster"):
+                del layer.self_attn.kv_cluster
+        klass.update_kv = spy
+        with torch.no_grad():
+            out = model.generate(ids, max_new_tokens=4, do_sample=False, use_cache=True, return_dict_in_generate=True)
+    finally:
+        klass.update_kv = orig
+        mp.replace_llama("fullkv")
+    assert len(seen) == 2 and out.sequences.shape[1] == 404
+    for li, (cl, k, q, v, lens, klen_sum, max_k, cu) in enumerate(seen):
+        kf, vf, olens, caps, idx, sc = oracle.ragged(q.cpu(), k.cpu(), v.cpu(), 8, 72, 7, "maxpool", 0.2, True,
+                                                     head_cap[li] if method == "headkv" else None)
+        assert lens == olens.tolist() and klen_sum == int(olens.sum()) and max_k == int(olens.max())
+        assert cu == [0] + torch.cumsum(olens, 0).tolist()
+        layer = out.past_key_values.layers[li]
+        assert layer.appended == 3 and layer.get_seq_length() == 403
+        row = 0
+        for h, (ks, vs) in enumerate(layer.segments()):                        # prefill rows == the oracle's flattened cache
+            ln = lens[h]
+            assert torch.equal(G.bits(ks[:ln]), G.bits(kf[row:row + ln])) and torch.equal(G.bits(vs[:ln]), G.bits(vf[row:row + ln]))
+            assert ks.shape[0] == ln + 3
+            row += ln
+    # the cluster API alone (no slack): exactly the reference's return value
+    cl, k, q, v = seen[0][0], seen[0][1], seen[0][2], seen[0][3]
+    kf2, vf2 = orig(cl, k, q, v)
+    kf, vf, olens, *_ = oracle.ragged(q.cpu(), k.cpu(), v.cpu(), 8, 72, 7, "maxpool", 0.2, True, head_cap[0] if method == "headkv" else None)
+    assert torch.equal(G.bits(kf2), G.bits(kf)) and torch.equal(G.bits(vf2), G.bits(vf)) and kf2.shape[0] == int(olens.sum())

@@ -14,7 +14,8 @@ import torch
 
 import golden_util as G
 
-SCORED = lambda m: m["method"] != "streamingllm" and not m["passthrough"]          # noqa: E731
+SCORED = lambda m: m["method"] in ("snapkv", "pyramidkv", "h2o") and not m["passthrough"]          # noqa: E731
+RAGGED = lambda m: m["method"] in ("adakv", "headkv")                               # noqa: E731
 SMALL = lambda m: SCORED(m) and m["L"] <= 1100                                      # noqa: E731
 CPU_BIG = ["C2_snapkv_8k_bf16", "C4_pyramidkv_8k_layer0", "C4_pyramidkv_8k_layer16"]   # (C3 H2O 8k: GPU suite)
 
@@ -132,3 +133,26 @@ def test_dtype_helpers(oracle):
     tb = x.to(torch.bfloat16).view(torch.int16).to(torch.int32) & 0xFFFF
     assert th.tolist() == [L.kvco_f32_to_f16(float(v)) for v in x.tolist()]
     assert tb.tolist() == [L.kvco_f32_to_bf16(float(v)) for v in x.tolist()]
+
+
+@pytest.mark.parametrize("name", G.names(lambda m: RAGGED(m) and not m["passthrough"] and m["L"] <= 1100))
+def test_adakv_headkv_against_reference(oracle, name):
+    """the oracle's restatement of AdaKVCluster / HeadKVCluster.update_kv (pyramidkv_utils.py:674-757, :813-878)
+    against the imported reference's golden vectors: per-head lengths, the indices every head keeps (a prefix of torch-CPU's
+    descending sort = libstdc++ std::sort, tie order included) and the flattened K / V byte for byte — every dtype.  (The two
+    8k x 32-head fixtures are checked by the GPU suite, which also runs the oracle on them.)"""
+    m, arr = G.MANIFEST[name], G.arrays(name)
+    q, k, v = _inputs(m)
+    g = m["Hq"] // m["Hkv"]
+    kf, vf, lens, caps, idx, sc = oracle.ragged(q, k[:, ::g].contiguous(), v[:, ::g].contiguous(), m["W"], m["cap"], m["kernel"],
+                                                m["pooling"], m.get("floor", 0.2), m.get("normalize", True), m.get("head_capacity"))
+    ref_lens = torch.from_numpy(arr["head_lens"])
+    assert torch.equal(lens, ref_lens)
+    kept = torch.from_numpy(arr["kept_indices"])
+    for h in range(m["Hq"]):
+        c = int(ref_lens[h]) - m["W"]
+        assert torch.equal(idx[h, :c], kept[h, :c])
+    assert list(kf.shape) == m["out_shape"] and G.sha(kf) == m["k_out_sha256"] and G.sha(vf) == m["v_out_sha256"]
+    ref_sc = G.from_bits(arr["scores"], G.DT[m["dtype"]])
+    d = G.ulp_diff(sc, ref_sc)
+    assert int(d.max()) <= (32 if m["dtype"] == "fp32" else 0)

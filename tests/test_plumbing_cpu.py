@@ -105,13 +105,13 @@ def test_replace_llama_and_mistral_rebind_and_restore():
     MA = transformers.models.mistral.modeling_mistral.MistralAttention
     orig_l, orig_m = LA.forward, MA.forward
     try:
-        for method in ("pyramidkv", "snapkv", "h2o", "streamingllm"):
+        for method in ("pyramidkv", "snapkv", "h2o", "streamingllm", "adakv", "headkv"):
             mp.replace_llama(method); mp.replace_mistral(method)
             assert LA.forward.kvc_method == method and MA.forward.kvc_method == method
         mp.replace_llama("no-such-method")               # unknown strings patch nothing (monkeypatch.py:19-87)
-        assert LA.forward.kvc_method == "streamingllm"
+        assert LA.forward.kvc_method == "headkv"
         with pytest.raises(NotImplementedError):
-            mp.replace_llama("adakv")
+            mp.replace_llama("cam")
     finally:
         mp.replace_llama("fullkv"); mp.replace_mistral("fullkv")
     assert LA.forward is orig_l and MA.forward is orig_m
