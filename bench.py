@@ -41,7 +41,7 @@ CONFIGS = {
                    desc="SnapKV 8k->128, W=32 (needle-runner window)"),
     "c4": dict(method="pyramidkv", L=8000, cap=128, W=8, kernel=7, pooling="maxpool", dtype=torch.bfloat16, prompts=32,
                desc="PyramidKV 8k, total budget 128x32 (k_l = 234..17)"),
-    "c5": dict(method="pyramidkv", L=32000, cap=2048, W=8, kernel=7, pooling="maxpool", dtype=torch.bfloat16, prompts=6,
+    "c5": dict(method="pyramidkv", L=32000, cap=2048, W=8, kernel=7, pooling="maxpool", dtype=torch.bfloat16, prompts=6, sets=1,
                desc="PyramidKV Mistral-7B shapes, 32k -> 2048 (k_l = 3978..103)"),
     "c3": dict(method="h2o", L=8000, cap=128, W=8, kernel=7, pooling=None, dtype=torch.bfloat16, layers=4, prompts=1,
                desc="H2O heavy-hitter scoring, Llama-3-8B shapes, seq_len=8000 -> 128, bf16 (all 8000 query rows score; "
@@ -300,12 +300,14 @@ def cpu_baseline(cfg, budget_s=12.0, dev=None):
                 g = HQ // HKV
                 heads = [g * i + (i % g) for i in range(HKV)]
                 qo = q[:, heads].contiguous()
+                sc_h2o = O.scores(qo, k, W, cfg["kernel"], "avgpool", full_rows=True, dot_mode=O.DOT_CHAIN, sum_mode=O.SUM_TORCH16,
+                                  n_threads=threads)                  # (0.07 Tflop on the host cores: once, for both tie modes)
             for tie, otie in (("canonical", O.TIES_CANON), ("torch_cpu", O.TIES_TORCH)):
                 got = _kvc.compress(METHODS[cfg["method"]], qd, kd, vd, W, n_keep, cfg["kernel"], pool, tie,
                                     return_indices=True, return_scores=True)
                 gi, gs = got[2][0].cpu(), got[3][0].cpu()
                 if h2o:
-                    sc = O.scores(qo, k, W, cfg["kernel"], "avgpool", full_rows=True, dot_mode=O.DOT_CHAIN, sum_mode=O.SUM_TORCH16, n_threads=threads)
+                    sc = sc_h2o
                     idx, _ = O.topk(sc, n_keep, otie, n_threads=threads)
                     ko = O.gather(k, idx, W, HKV)
                     gi, gs, gk = gi[heads], gs[heads], got[0][:, heads].cpu()
@@ -340,7 +342,8 @@ def main():
                     help="prompts in flight: 2 alternates consecutive prompts between two HIP streams (a serving stack's overlap: "
                          "the latency-bound exact top-k of one prompt runs beside the K scan of the next)")
     ap.add_argument("--prompts", type=int, default=0, help="prompts per step (0: the config's default, sized for ~20 ms steps)")
-    ap.add_argument("--sets", type=int, default=2, help="distinct resident prompts the step cycles over")
+    ap.add_argument("--sets", type=int, default=0, help="distinct resident prompts the step cycles over (0: the config's default, 2; "
+                                                          "1 at 32k, where one prompt's K is 2 GB and generating it takes a while)")
     ap.add_argument("--streams", type=int, default=16, help="calls mode: HIP streams the 32 independent layer calls are spread over")
     ap.add_argument("--dot-mode", default="exact", choices=["exact", "mfma16"],
                     help="exact: f32-MFMA fmaf chain (bit-identical to the oracle); mfma16: packed bf16 MFMA scan (tolerance mode)")
@@ -368,7 +371,7 @@ def main():
         a.mode, a.in_flight, a.streams = "calls", 1, 1       # compute-bound single calls
     per_step = a.prompts or cfg["prompts"]
     ks = layer_budgets(cfg)
-    n_sets = max(a.sets, a.in_flight)
+    n_sets = max(a.sets or cfg.get("sets", 2), a.in_flight)
     inputs = [make_inputs(cfg, dev, rank_seed(rank) + 100 * s) for s in range(n_sets)]
     fl = side_streams(dev, 2) if a.in_flight == 2 else None
     prompts = [Prompt(cfg, dev, a.tie_mode, a.mode, inputs[s], ks, a.streams if a.mode == "calls" else 1,

@@ -183,10 +183,7 @@ def make_ragged_forward(method, apply_rotary_pos_emb, eager_attention_forward, r
             layer = layers[self.layer_idx]
             if layer.get_seq_length() == 0:                                  # prefill (:2322)
                 self.kv_cluster.update_kv(key_states, query_states, value_states, slack=pu.RAGGED_SLACK)
-                r = self.kv_cluster.ragged
-                if r is None:                                                # "not compress" (:696): every head keeps all rows
-                    raise NotImplementedError("AdaKV / HeadKV with max_capacity_prompt above the prompt length: nothing to compress")
-                layer.prefill(r, key_states.shape[-2])
+                layer.prefill(self.kv_cluster.ragged, key_states.shape[-2])    # ("not compress", :696: every head keeps all rows)
             else:                                                            # decode (:2363-2390)
                 attn_output = layer.decode_attend(query_states, key_states, value_states, self.scaling)
                 return self.o_proj(attn_output.reshape(*input_shape, -1)), None

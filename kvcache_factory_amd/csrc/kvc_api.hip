@@ -220,7 +220,7 @@ int enqueue_select(const kvc_params* p, const Items& it, bool fuse, void* exact_
     const int n_sel = p->q_len - p->window;
     if (p->tie_mode == KVC_TIES_CANONICAL) {
         if (it.k_max > 16384) return fail(KVC_ERR_UNSUPPORTED, "tie_mode canonical: k=%d > 16384 (the LDS sort of the selected set) not built", it.k_max);
-        if (n_sel > 65536) return fail(KVC_ERR_UNSUPPORTED, "tie_mode canonical: more than 65536 candidates per head not built (torch_cpu has no such limit)");
+        if (n_sel > 131072) return fail(KVC_ERR_UNSUPPORTED, "tie_mode canonical: more than 131072 candidates per head not built (torch_cpu has no such limit)");
     } else if ((int64_t)it.k_max * 64 <= (int64_t)n_sel && it.k_max > 18000) {
         return fail(KVC_ERR_UNSUPPORTED, "tie_mode torch_cpu: a partial_sort heap of k=%d does not fit in LDS", it.k_max);
     }

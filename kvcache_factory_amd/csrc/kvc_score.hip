@@ -936,7 +936,7 @@ static void launch_softmax_pool_t(const ScoreArgs& a, hipStream_t st) {
             dim3 g((unsigned)(a.bsz * a.n_q_heads), (unsigned)a.n_items);
             constexpr int KEEP = 64 / WV;                     // iterations whose exponentials stay in registers
             static LdsCache c_keep = {}, c_loop = {};
-            if (KEEP >= 2 && iters <= KEEP) {
+            if (KEEP >= 2 && iters <= KEEP && !(a.stage_mask & 256)) {
                 (void)ensure_lds(reinterpret_cast<const void*>(&softmax_pool_kernel<DT, WV, (KEEP >= 2 ? KEEP : 0)>), kSoftmaxLds, c_keep);
                 hipLaunchKernelGGL((softmax_pool_kernel<DT, WV, (KEEP >= 2 ? KEEP : 0)>), g, dim3(SP_THREADS), kSoftmaxLds, st, a);
             } else {

@@ -294,6 +294,7 @@ static int launch_dt(const SelectArgs& a, hipStream_t st) {
     if (n <= 16384) return launch_t<DT, 32, 512>(a, st);
     if (n <= 32768) return launch_t<DT, 64, 512>(a, st);
     if (n <= 65536) return launch_t<DT, 64, 1024>(a, st);
+    if (n <= 131072) return launch_t<DT, 128, 1024>(a, st);   // 128k contexts: 128 keys per thread (they spill: correct, not quick)
     return KVC_ERR_UNSUPPORTED;
 }
 

@@ -275,8 +275,15 @@ class _RaggedCluster:
             k = key_states.repeat_interleave(g, 1) if g > 1 else key_states
             v = value_states.repeat_interleave(g, 1) if g > 1 else value_states
             self._init_metadata(num_heads, [q_len] * num_heads, key_states.device)
-            self.ragged = None
-            return k.reshape(-1, head_dim), v.reshape(-1, head_dim)
+            kf, vf = k.reshape(-1, head_dim), v.reshape(-1, head_dim)
+            if slack:                                                          # the same rows with spare rows behind every head
+                kf = torch.cat([kf.view(num_heads, q_len, head_dim), kf.new_empty(num_heads, slack, head_dim)], 1).reshape(-1, head_dim)
+                vf = torch.cat([vf.view(num_heads, q_len, head_dim), vf.new_empty(num_heads, slack, head_dim)], 1).reshape(-1, head_dim)
+            dev = key_states.device
+            self.ragged = dict(k_flat=kf, v_flat=vf, lens=[q_len] * num_heads, slack=slack,
+                               seg_off=torch.arange(num_heads, dtype=torch.int64, device=dev) * (q_len + slack),
+                               seg_len=torch.full((num_heads,), q_len, dtype=torch.int32, device=dev))
+            return kf, vf
         r = _kvc.ragged_compress(self._method, query_states, key_states, value_states, self.window_size, self.base_capacity,
                                  self.kernel_size, self.pooling, getattr(self, "floor_ratio", 0.0), getattr(self, "normalize", False),
                                  self._capacities(), slack=slack, tie_mode=TIE_MODE)

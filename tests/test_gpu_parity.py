@@ -923,8 +923,52 @@ def test_ragged_clusters_and_patched_model(kvc, oracle, gpu_device, method):
             assert torch.equal(G.bits(ks[:ln]), G.bits(kf[row:row + ln])) and torch.equal(G.bits(vs[:ln]), G.bits(vf[row:row + ln]))
             assert ks.shape[0] == ln + 3
             row += ln
+    # a prompt shorter than the budget ("not compress", :696): every head keeps all its rows, decode continues over them
+    try:
+        mp.replace_llama(method)
+        for layer in model.model.layers:
+            layer.self_attn.config.max_capacity_prompt = 4096
+            if hasattr(layer.self_attn, "kv_cluster"):
+                del layer.self_attn.kv_cluster
+        with torch.no_grad():
+            short = model.generate(ids[:, :50], max_new_tokens=3, do_sample=False, use_cache=True, return_dict_in_generate=True)
+            mp.replace_llama("fullkv")
+            full = model.generate(ids[:, :50], max_new_tokens=3, do_sample=False, use_cache=True, return_dict_in_generate=True)
+    finally:
+        mp.replace_llama("fullkv")
+        for layer in model.model.layers:
+            layer.self_attn.config.max_capacity_prompt = 72
+    assert torch.equal(short.sequences, full.sequences) and short.past_key_values.layers[0].lens == [50] * 8
     # the cluster API alone (no slack): exactly the reference's return value
     cl, k, q, v = seen[0][0], seen[0][1], seen[0][2], seen[0][3]
     kf2, vf2 = orig(cl, k, q, v)
     kf, vf, olens, *_ = oracle.ragged(q.cpu(), k.cpu(), v.cpu(), 8, 72, 7, "maxpool", 0.2, True, head_cap[0] if method == "headkv" else None)
     assert torch.equal(G.bits(kf2), G.bits(kf)) and torch.equal(G.bits(vf2), G.bits(vf)) and kf2.shape[0] == int(olens.sum())
+
+
+@pytest.mark.parametrize("n,k", [(131064, 128), (131064, 300), (131064, 2040), (131064, 5000), (70000, 100)])
+@pytest.mark.parametrize("dtype,levels", [(torch.bfloat16, 40), (torch.float16, 3000)])
+def test_exact_ties_beyond_65536_candidates(kvc, oracle, gpu_device, n, k, dtype, levels):
+    """128k contexts (Llama-3.1): more than 65 536 candidates per head.  The packed (key << 16 | index) heap nodes need
+    indices below 65 536; longer rows take 64-bit nodes — partial_sort with the lane-parallel heap (k <= 128), the scalar heap
+    (k = 300, 2040) and nth_element + sort with the array in the workspace (k = 5000) — indices identical to the oracle's
+    libstdc++ run, order included."""
+    sc = _tie_heavy_scores(2, n, dtype, 77 + n + k, levels)
+    want, _ = oracle.topk(sc, k, oracle.TIES_TORCH)
+    got = kvc.select(sc[None].to(gpu_device), k, "torch_cpu")[0].cpu()
+    assert torch.equal(got, want)
+    wantc, _ = oracle.topk(sc, k, oracle.TIES_CANON)                       # canonical ties: 128 keys per thread up to 131 072
+    gotc = kvc.select(sc[None].to(gpu_device), k, "canonical")[0].cpu()
+    assert torch.equal(gotc, wantc)
+
+
+def test_compress_at_128k_context(kvc, oracle, gpu_device):
+    """kvc_compress end to end at q_len = 131072 (2 query heads over 1 KV head to keep the oracle quick): scores bit-exact,
+    torch-CPU-tie indices and K' / V' bytes equal to the oracle's."""
+    L, W, keep = 131072, 8, 2040
+    q, k, v = G.synth.make_qkv(2, 1, L, 128, torch.bfloat16, 131, device=gpu_device)
+    ko, vo, idx, sc = kvc.compress(kvc.SNAPKV, q, k, v, W, keep, 7, "maxpool", "torch_cpu", return_indices=True, return_scores=True)
+    ko_, vo_, io_, sc_ = oracle.compress(q.cpu(), k.cpu(), v.cpu(), W, keep, 7, "maxpool", dot_mode=oracle.DOT_CHAIN,
+                                         sum_mode=oracle.SUM_TORCH16, tie_mode=oracle.TIES_TORCH)
+    assert torch.equal(G.bits(sc[0]), G.bits(sc_)) and torch.equal(idx[0].cpu(), io_)
+    assert torch.equal(G.bits(ko), G.bits(ko_)) and torch.equal(G.bits(vo), G.bits(vo_))
