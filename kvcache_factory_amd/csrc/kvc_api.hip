@@ -186,6 +186,7 @@ int enqueue_scores(const kvc_params* p, const Layout& l, const Items& it, char* 
     a.dbg = nullptr;
 #if defined(KVC_STAMPS)
     a.dbg = reinterpret_cast<unsigned long long*>(it.scores[0]);   // diagnostic build: stamps land in scores_out
+    if ((p->debug_stage_mask & 7) == 6 && it.idx[0]) a.dbg = reinterpret_cast<unsigned long long*>(it.idx[0]);   // softmax stamps: item 0's idx_out
 #endif
     a.sqrt_d = (float)std::sqrt((double)p->head_dim);   // math.sqrt(head_dim) -> fp32 (pyramidkv_utils.py:317)
     const int rc = kvc::launch_scores(a, p->dtype, p->head_dim, st);

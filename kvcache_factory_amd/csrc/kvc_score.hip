@@ -47,8 +47,17 @@ __device__ __forceinline__ ScoreView view_of(const ScoreArgs& a, int item) {
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         if (a.dbg && lane == 0) a.dbg[((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + (slot)] = t_; \
     } while (0)
+#define KVC_SPSTAMP(slot)                                                                                     \
+    do {                                                                                                      \
+        unsigned long long t_;                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if (a.dbg && threadIdx.x == 0 && blockIdx.y == 0) a.dbg[blockIdx.x * 8 + (slot)] = t_;                \
+    } while (0)
 #else
 #define KVC_STAMP(slot) do { } while (0)
+#define KVC_SPSTAMP(slot) do { } while (0)
 #endif
 
 // Pull the element with parity kh (= lane >> 5) of bf16/fp16 pair s out of a 16-byte chunk (8 elements), or of fp32
@@ -547,6 +556,25 @@ __device__ __forceinline__ void load_logits(const typename Dt<DT>::raw* src, int
     }
 }
 
+// The W logits of one key from 16-byte vectors already in registers (compile-time W, a multiple of 16 bytes).
+template <int DT, int WV>
+__device__ __forceinline__ void widen_logits(const uint4 (&v)[(WV * Dt<DT>::esize) / 16 > 0 ? (WV * Dt<DT>::esize) / 16 : 1], float (&x)[WV]) {
+    constexpr int ES = Dt<DT>::esize, PER16 = 16 / ES;
+#pragma unroll
+    for (int c = 0; c < WV / PER16; ++c) {
+        const uint32_t wd[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (ES == 2) {
+                x[c * 8 + 2 * e] = Dt<DT>::ld((uint16_t)(wd[e] & 0xffffu));
+                x[c * 8 + 2 * e + 1] = Dt<DT>::ld((uint16_t)(wd[e] >> 16));
+            } else {
+                x[c * 4 + e] = u2f(wd[e]);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Softmax denominators in torch's own order (aten vec::reduce_all on 16 fp32 lanes, the order of softmax's row sum on
 // the reference's AVX-512 host — oracle: sum_torch16): chain l, l = 0..15, adds the exponentials of keys l, l+16, l+32, ...
@@ -758,7 +786,22 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
     float* const seg = stage;                                     // [4][1024]   (pass 2; 4096 <= 2 * ESTAGE)
     const raw* const lg = reinterpret_cast<const raw*>(vw.logits) + (int64_t)hb * L * W;
 
+    // the head's logits are requested BEFORE the row maxima are fetched and reduced: two dependent trips to memory (tile
+    // maxima, then logits) were a third of a workgroup's lifetime
+    KVC_SPSTAMP(0);
+    constexpr int VPK = (W * (int)sizeof(raw)) / 16;               // 16-byte vectors per key
+    uint4 rawx[KEEP > 0 ? KEEP : 1][VPK > 0 ? VPK : 1];
+    if constexpr (KEEP > 0) {
+#pragma unroll
+        for (int it = 0; it < KEEP; ++it) {
+            const int key = it * SP_THREADS + tid;
+#pragma unroll
+            for (int c = 0; c < VPK; ++c)
+                rawx[it][c] = (it < iters && key < L) ? reinterpret_cast<const uint4*>(lg + (int64_t)key * W)[c] : make_uint4(0, 0, 0, 0);
+        }
+    }
     block_row_max(vw.pmax + (int64_t)hb * a.n_tiles * W, a.n_tiles, W, m, scratch);
+    KVC_SPSTAMP(1);
     float mr[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) mr[w] = m[w];
@@ -769,10 +812,7 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
     if constexpr (KEEP > 0) {
         float x[KEEP][W];
 #pragma unroll
-        for (int it = 0; it < KEEP; ++it) {
-            const int key = it * SP_THREADS + tid;
-            if (it < iters && key < L) load_logits<DT, W>(lg + (int64_t)key * W, W, x[it]);
-        }
+        for (int it = 0; it < KEEP; ++it) widen_logits<DT, W>(rawx[it], x[it]);
 #pragma unroll
         for (int it = 0; it < KEEP; ++it) {
             const int key = it * SP_THREADS + tid;
@@ -782,6 +822,7 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
                 e[it][w] = (it < iters && key < L) ? ex.x : 0.0f; e[it][w + 1] = (it < iters && key < L) ? ex.y : 0.0f;
             }
         }
+        KVC_SPSTAMP(2);
         // (a compile-time it / w inside the staging loop: the kept values are addressed as registers)
         const int cw = tid >> 4, cl = tid & 15;
         constexpr int groups = (W + ESTAGE_ROWS - 1) / ESTAGE_ROWS;
@@ -803,8 +844,10 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
                         for (int r = 0; r < ESTAGE_ROWS; ++r)
                             if (g * ESTAGE_ROWS + r < W) buf[r * EPITCH + tid] = e[it][(g * ESTAGE_ROWS + r) < W ? (g * ESTAGE_ROWS + r) : 0];
                         __syncthreads();
+                        if (it == 1) KVC_SPSTAMP(6);
                         if ((cw / ESTAGE_ROWS) == g && cw < W)
                             acc = chain16_add(acc, buf + (cw % ESTAGE_ROWS) * EPITCH + cl, it * SP_THREADS, cl, L);
+                        if (it == 1) KVC_SPSTAMP(7);
                         ++fill;
                     }
                 }
@@ -839,6 +882,7 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
         vw.rowsum[(int64_t)hb * W + (tid >> 4)] = sum;
     }
     __syncthreads();                                              // rinv visible; the stages are free for the ring
+    KVC_SPSTAMP(3);
     float ri[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) ri[w] = rinv[w];
@@ -846,21 +890,25 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
     // pass 2: p = round(e / sum), window sum (cascade), round; pooling one iteration behind through the segment ring
     const int pad = a.pooling == KVC_POOL_NONE ? 0 : a.kernel_size / 2;
     raw* const out = reinterpret_cast<raw*>(vw.scores) + (int64_t)hb * n;
+    // The per-key window sums go to LDS: all of them at once when the row fits the stage area (up to 16 640 keys: ONE barrier
+    // between the sums and the pooling), else through a ring of four 1024-key segments, pooling one iteration behind.
+    const bool flat = iters * SP_THREADS <= 2 * ESTAGE;
+    const int ring = flat ? ~0 : (4 * SP_THREADS - 1);
     auto pool_iteration = [&](int itp) {
         const int jo = itp * SP_THREADS + tid;
         if (jo >= n) return;
         float c;
         if (a.pooling == KVC_POOL_NONE) {
-            c = seg[(itp & 3) * SP_THREADS + tid];
+            c = seg[jo & ring];
         } else {
             const int lo = jo - pad < 0 ? 0 : jo - pad;
             const int hi = jo - pad + a.kernel_size > n ? n : jo - pad + a.kernel_size;
             if (a.pooling == KVC_POOL_MAX) {
                 c = -__builtin_inff();
-                for (int i = lo; i < hi; ++i) { const float v = seg[i & (4 * SP_THREADS - 1)]; c = v > c ? v : c; }
+                for (int i = lo; i < hi; ++i) { const float v = seg[i & ring]; c = v > c ? v : c; }
             } else {
                 float acc = 0.0f;
-                for (int i = lo; i < hi; ++i) acc = acc + seg[i & (4 * SP_THREADS - 1)];
+                for (int i = lo; i < hi; ++i) acc = acc + seg[i & ring];
                 c = rnd<DT>(acc / (float)a.kernel_size);
             }
         }
@@ -878,15 +926,28 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
         return rnd<DT>(a.window_mean ? cs.result() / (float)W : cs.result());
     };
     if constexpr (KEEP > 0) {
+        if (flat) {
 #pragma unroll
-        for (int it = 0; it <= KEEP; ++it) {
-            if (it <= iters) {
+            for (int it = 0; it < KEEP; ++it)
                 if (it < iters) {
                     const int key = it * SP_THREADS + tid;
-                    seg[(it & 3) * SP_THREADS + tid] = key < n ? window_sum(e[it < KEEP ? it : 0]) : 0.0f;
+                    seg[key] = key < n ? window_sum(e[it]) : 0.0f;
                 }
-                __syncthreads();
-                if (it >= 1) pool_iteration(it - 1);
+            __syncthreads();
+            KVC_SPSTAMP(4);
+            for (int it = 0; it < iters; ++it) pool_iteration(it);
+            KVC_SPSTAMP(5);
+        } else {
+#pragma unroll
+            for (int it = 0; it <= KEEP; ++it) {
+                if (it <= iters) {
+                    if (it < iters) {
+                        const int key = it * SP_THREADS + tid;
+                        seg[(it & 3) * SP_THREADS + tid] = key < n ? window_sum(e[it < KEEP ? it : 0]) : 0.0f;
+                    }
+                    __syncthreads();
+                    if (it >= 1) pool_iteration(it - 1);
+                }
             }
         }
     } else {
@@ -904,10 +965,16 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
                     }
                     sv = window_sum(ev);
                 }
-                seg[(it & 3) * SP_THREADS + tid] = sv;
+                seg[flat ? key : (it & 3) * SP_THREADS + tid] = sv;
             }
+            if (!flat) {
+                __syncthreads();
+                if (it >= 1) pool_iteration(it - 1);
+            }
+        }
+        if (flat) {
             __syncthreads();
-            if (it >= 1) pool_iteration(it - 1);
+            for (int it = 0; it < iters; ++it) pool_iteration(it);
         }
     }
 }
