@@ -234,6 +234,9 @@ int enqueue_select(const kvc_params* p, const Items& it, bool fuse, void* exact_
     while (s.pow2 < s.k_max) s.pow2 <<= 1;
     if (fuse) { s.fuse = 1; s.gk = gather_args(p, it, 0, true); s.gv = gather_args(p, it, 1, true); }
     if (p->tie_mode == KVC_TIES_TORCH_CPU) {
+#if defined(KVC_STAMPS)
+        if (p->debug_stage_mask & 32) s.fuse = 2;            // diag build: phase stamps over the index output (no gather follows)
+#endif
         const int rc = kvc::launch_select_exact(s, p->dtype, exact_scratch, st);
         if (rc == KVC_ERR_WORKSPACE) return fail(rc, "tie_mode torch_cpu at n=%d needs the workspace (kvc_workspace_bytes)", s.n);
         if (rc) return fail(rc, "exact select launch failed");
@@ -330,6 +333,9 @@ int run_items(const kvc_params* p, Items& it, void* workspace, size_t workspace_
     const bool fuse = it.k_max <= kvc::kFuseGatherMaxK && p->tie_mode == KVC_TIES_CANONICAL;
     if (int rc = enqueue_select(p, it, fuse, ws + l.total * (size_t)it.n, st)) return rc;
     if (fuse) return KVC_OK;
+#if defined(KVC_STAMPS)
+    if (dbg & 32) return KVC_OK;                             // the index output holds phase stamps in this build: no gather
+#endif
     const kvc::GatherArgs gk = gather_args(p, it, 0, true), gv = gather_args(p, it, 1, true);
     return enqueue_gather(&gk, &gv, st);
 }

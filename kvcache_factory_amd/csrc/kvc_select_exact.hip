@@ -217,20 +217,75 @@ __device__ __forceinline__ void partial_sort_wave(const typename Dt<DT>::raw* s,
 // is at most 16 long with runs already ordered among themselves, so the final place of element i is
 // i - #(j in [i-15, i): key_j < key_i) + #(j in (i, i+15]: key_j > key_i) — 30 reads per element, all lanes at once.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kSmallRange = 1024;                        // partitions up to this many elements keep their lists in LDS
-constexpr size_t kSmallListBytes = (size_t)(kSmallRange / 2 + 2) * 8;
+#if defined(KVC_STAMPS)
+#define KVC_XSTAMP(slot)                                                                     \
+    do {                                                                                     \
+        unsigned long long t_;                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");         \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        xstamps_[slot] = t_;                                                                 \
+    } while (0)
+#define KVC_XCOUNT(slot) (++xstamps_[slot])
+#define KVC_XTIC(var)                                                                        \
+    unsigned long long var;                                                                  \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    } while (0)
+#define KVC_XACC(slot, a, b) (xstamps_[slot] += (b) - (a))
+#else
+#define KVC_XTIC(var) do { } while (0)
+#define KVC_XACC(slot, a, b) do { } while (0)
+#define KVC_XSTAMP(slot) do { } while (0)
+#define KVC_XCOUNT(slot) do { } while (0)
+#endif
+// Position lists of one partition: the first cap = m/2 + 2 left stoppers (ascending) and the last `ring` right stoppers
+// (a ring buffer, newest = highest position), as offsets from `first`.  16-bit offsets in LDS whenever the range's lists
+// fit the list region (m <= 65536), 32-bit in the caller's workspace otherwise: a list round trip through the workspace
+// costs several memory latencies per partition, and nth_element makes a dozen of them one after the other.
+constexpr size_t kMinListBytes = 1024;                   // the two 65-int tables of partition_pivot_small; lists for m < 500
+__host__ __device__ inline size_t list_bytes_for(int m) {   // LDS bytes of the 16-bit lists of an m-element range
+    const int cap = m / 2 + 2, ring = cap > 64 ? cap : 64;
+    return (size_t)(cap + ring) * 2;
+}
+// Pointers carry their address space (LDS = 3, global = 1): a pointer that may be either compiles to flat_load / flat_store,
+// whose LDS round trip is several times a ds_read's and which serialises on both memory counters — on this
+// latency-bound kernel that alone cost a factor of two.  AP = the array's element type WITH its address space.
+typedef __attribute__((address_space(3))) u64 lds_u64;
+typedef __attribute__((address_space(1))) u64 glb_u64;
+typedef __attribute__((address_space(3))) int lds_int;
+typedef __attribute__((address_space(1))) int glb_int;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(1))) int64_t glb_i64;
+template <class AP>
+struct ArrT {                // the view kvc_stl_emul.h's routines take, on an address-space-typed array
+    AP* p;
+    __device__ __forceinline__ u64 get(int i) const { return uni((u64)p[i]); }
+    __device__ __forceinline__ void set(int i, u64 v) const { p[i] = v; }
+    __device__ __forceinline__ void swap(int i, int j) const { const u64 a = get(i), b = get(j); p[i] = b; p[j] = a; }
+};
+template <class AP>
 struct WaveSel {
-    u64* arr;
-    int* Lbig;                                           // position lists for any range (caller's workspace)
-    int* Rbig;
-    int* small;                                          // LDS lists for ranges <= kSmallRange, or null
+    typedef ArrT<AP> Arr;
+    AP* arr;
+    glb_int* Lbig;                                       // 32-bit lists for any range (caller's workspace, n/2 + 2 each)
+    glb_int* Rbig;
+    lds_int* small;                                      // LDS list region (>= kMinListBytes)
     int lane;
+    int small_bytes = (int)kMinListBytes;                // its size
+#if defined(KVC_STAMPS)
+    unsigned long long* xstamps_ = nullptr;              // the kernel's stamp array (diagnostic build)
+#endif
     __device__ __forceinline__ static uint32_t key(u64 v) { return (uint32_t)(v >> 32); }
     __device__ __forceinline__ u64 get(int i) const { return uni(arr[i]); }
 
-    // the two compaction passes of partition(): left stoppers in ascending, right stoppers in descending position order
-    template <int UF>
-    __device__ __forceinline__ void scan(int first, int last, uint32_t pk, int cap, int* Lp, int* Rp, int& NL, int& NR) {
+    // ONE pass over [first, last): left stoppers (!(key > pk)) in ascending position order, capped at `cap` entries; right
+    // stoppers (!(pk > key)) in ascending order too, into a ring of `ring` >= max(cap, 64) slots, so that the serial scan's
+    // t-th right stopper FROM THE RIGHT is ring[(NR - 1 - t) mod ring] for every t < cap.
+    template <class LT, int UF>
+    __device__ __forceinline__ void scan(int first, int last, uint32_t pk, int cap, int ring, LT* Lp, LT* Rr, int& NL, int& NR, int& nrm) {
         for (int base = first; base < last; base += 64 * UF) {
             uint32_t kx[UF];
 #pragma unroll
@@ -238,57 +293,58 @@ struct WaveSel {
 #pragma unroll
             for (int u = 0; u < UF; ++u) {
                 const int i = base + u * 64 + lane;
-                const bool sl = i < last && !(kx[u] > pk);
-                const u64 mask = __ballot(sl);
-                const int rank = NL + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-                if (sl && rank < cap) Lp[rank] = i;
-                NL += __builtin_popcountll(mask);
-            }
-        }
-        for (int top = last; top > first; top -= 64 * UF) {
-            uint32_t kx[UF];
-#pragma unroll
-            for (int u = 0; u < UF; ++u) { const int i = top - 1 - u * 64 - lane; kx[u] = i >= first ? key(arr[i]) : 0u; }
-#pragma unroll
-            for (int u = 0; u < UF; ++u) {
-                const int i = top - 1 - u * 64 - lane;
-                const bool sr = i >= first && !(pk > kx[u]);
-                const u64 mask = __ballot(sr);
-                const int rank = NR + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-                if (sr && rank < cap) Rp[rank] = i;
-                NR += __builtin_popcountll(mask);
+                const bool sl = i < last && !(kx[u] > pk), sr = i < last && !(pk > kx[u]);
+                const u64 ml = __ballot(sl), mr = __ballot(sr);
+                const int rank = NL + __builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0));
+                if (sl && rank < cap) Lp[rank] = (i - first);
+                NL += __builtin_popcountll(ml);
+                int slot = nrm + __builtin_amdgcn_mbcnt_hi((uint32_t)(mr >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mr, 0));
+                if (slot >= ring) slot -= ring;
+                if (sr) Rr[slot] = (i - first);
+                const int c = __builtin_popcountll(mr);
+                NR += c;
+                nrm += c;
+                if (nrm >= ring) nrm -= ring;
             }
         }
     }
-    template <int US>
-    __device__ __forceinline__ void swap_pairs(int T, const int* Lp, const int* Rp) {
+    template <class LT>
+    __device__ __forceinline__ static int r_at(const LT* Rr, int nrm, int ring, int t) {      // t-th right stopper from the right
+        int e = nrm - 1 - t;
+        if (e < 0) e += ring;
+        return (int)Rr[e];
+    }
+    template <class LT, int US>
+    __device__ __forceinline__ void swap_pairs(int first, int T, const LT* Lp, const LT* Rr, int nrm, int ring) {
         for (int t0 = 0; t0 < T; t0 += 64 * US) {
             int l[US], r[US];
             u64 av[US], bv[US];
 #pragma unroll
-            for (int u = 0; u < US; ++u) { const int t = t0 + u * 64 + lane; l[u] = t < T ? Lp[t] : -1; r[u] = t < T ? Rp[t] : -1; }
+            for (int u = 0; u < US; ++u) {
+                const int t = t0 + u * 64 + lane;
+                l[u] = t < T ? first + (int)Lp[t] : -1;
+                r[u] = t < T ? first + r_at(Rr, nrm, ring, t) : -1;
+            }
 #pragma unroll
             for (int u = 0; u < US; ++u) if (l[u] >= 0) { av[u] = arr[l[u]]; bv[u] = arr[r[u]]; }
 #pragma unroll
             for (int u = 0; u < US; ++u) if (l[u] >= 0) { arr[l[u]] = bv[u]; arr[r[u]] = av[u]; }
         }
     }
-    __device__ int partition(int first, int last, int pivot) {
-        const uint32_t pk = key(get(pivot));
-        const int cap = (last - first) / 2 + 2;
-        // the sort phase makes hundreds of small partitions: their lists live in LDS (a list round trip through the
-        // workspace costs a memory latency per partition)
-        const bool use_small = small != nullptr && last - first <= kSmallRange;
-        int* const Lp = use_small ? small : Lbig;
-        int* const Rp = use_small ? small + (kSmallRange / 2 + 2) : Rbig;
-        int NL = 0, NR = 0;
+    template <class LT>
+    __device__ __forceinline__ int partition_t(int first, int last, uint32_t pk, LT* Lp, LT* Rr) {
+        const int m = last - first, cap = m / 2 + 2, ring = cap > 64 ? cap : 64;
+        int NL = 0, NR = 0, nrm = 0;
+        KVC_XTIC(x0_);
         // Loads are grouped UF chunks of 64 elements at a time: a long range in the workspace (n > 18000) is bound by memory
         // round trips, a short one (the hundreds of sort partitions) by the instructions of the padded trips.
-        const int m = last - first;
-        if (m > 8192) scan<16>(first, last, pk, cap, Lp, Rp, NL, NR);
-        else if (m > 256) scan<4>(first, last, pk, cap, Lp, Rp, NL, NR);
-        else scan<1>(first, last, pk, cap, Lp, Rp, NL, NR);
+        if (m > 16384) scan<LT, 32>(first, last, pk, cap, ring, Lp, Rr, NL, NR, nrm);
+        else if (m > 2048) scan<LT, 16>(first, last, pk, cap, ring, Lp, Rr, NL, NR, nrm);
+        else if (m > 256) scan<LT, 4>(first, last, pk, cap, ring, Lp, Rr, NL, NR, nrm);
+        else scan<LT, 1>(first, last, pk, cap, ring, Lp, Rr, NL, NR, nrm);
         __syncthreads();
+        KVC_XTIC(x1_);
+        KVC_XACC(12, x0_, x1_);
         int lim = NL < NR ? NL : NR;
         if (lim > cap) lim = cap;
         // l_t < r_t holds exactly for a prefix of t (l ascending, r descending): T by bisection over the wave — 64 probes
@@ -299,7 +355,7 @@ struct WaveSel {
             while (hi_t - lo_t > 0) {
                 const int span = hi_t - lo_t, step = (span + 63) / 64;    // probe t = lo_t + lane * step
                 const int t = lo_t + lane * step;
-                const bool ok = t < hi_t && Lp[t] < Rp[t];
+                const bool ok = t < hi_t && (int)Lp[t] < r_at(Rr, nrm, ring, t);
                 const u64 okm = __ballot(ok);
                 const int good = __builtin_popcountll(okm);               // probes 0 .. good-1 hold (prefix property)
                 if (good == 0) { hi_t = lo_t; break; }
@@ -311,11 +367,26 @@ struct WaveSel {
             }
             T = lo_t;
         }
-        if (T > 2048) swap_pairs<8>(T, Lp, Rp); else if (T > 128) swap_pairs<2>(T, Lp, Rp); else swap_pairs<1>(T, Lp, Rp);
-        const int lnext = T < NL ? uni(Lp[T]) : 0x7fffffff;
-        const int rlast = T > 0 ? uni(Rp[T - 1]) : 0x7fffffff;
+        KVC_XTIC(x2_);
+        KVC_XACC(13, x1_, x2_);
+        if (T > 2048) swap_pairs<LT, 8>(first, T, Lp, Rr, nrm, ring);
+        else if (T > 128) swap_pairs<LT, 2>(first, T, Lp, Rr, nrm, ring);
+        else swap_pairs<LT, 1>(first, T, Lp, Rr, nrm, ring);
+        const int lnext = T < NL ? first + uni((int)Lp[T]) : 0x7fffffff;
+        const int rlast = T > 0 ? first + uni(r_at(Rr, nrm, ring, T - 1)) : 0x7fffffff;
         __syncthreads();
+        KVC_XTIC(x3_);
+        KVC_XACC(14, x2_, x3_);
         return lnext < rlast ? lnext : rlast;
+    }
+    __device__ __forceinline__ int partition(int first, int last, int pivot) {
+        const uint32_t pk = key(get(pivot));
+        const int m = last - first, cap = m / 2 + 2;
+        if (m <= 65536 && list_bytes_for(m) <= (size_t)small_bytes) {
+            lds_u16* const l16 = (lds_u16*)small;
+            return partition_t<lds_u16>(first, last, pk, l16, l16 + cap);
+        }
+        return partition_t<glb_int>(first, last, pk, Lbig, Rbig);
     }
     // __unguarded_partition_pivot of a range of at most 64 elements (most calls of the sort phase), one element per lane
     // in registers: median-of-three and its swap by readlane, the two stopper sets as ballots, the pairing by popcounts
@@ -326,7 +397,7 @@ struct WaveSel {
         const uint32_t a = __builtin_amdgcn_readlane((uint32_t)v, l), b = __builtin_amdgcn_readlane((uint32_t)(v >> 32), l);
         return ((u64)b << 32) | a;
     }
-    __device__ __noinline__ int partition_pivot_small(int first, int last) {
+    __device__ __forceinline__ int partition_pivot_small_body(int first, int last) {
         const int m = last - first;                                       // 4 .. 64
         u64 x = lane < m ? arr[first + lane] : 0ull;
         // __move_median_to_first(first, first + 1, mid, last - 1)
@@ -348,8 +419,8 @@ struct WaveSel {
         const bool swl = isl && __builtin_popcountll(SR & above) >= t;
         const bool swr = isr && __builtin_popcountll(SL & (below_incl >> 1)) >= u;   // left stoppers strictly below
         const int T = __builtin_popcountll(__ballot(swl));
-        int* const tl = small;                                            // positions by rank (LDS, 2 x 65 ints)
-        int* const tr = small + 65;
+        lds_int* const tl = small;                                            // positions by rank (LDS, 2 x 65 ints)
+        lds_int* const tr = small + 65;
         if (isl) tl[t] = lane;
         if (isr) tr[u] = lane;
         __syncthreads();
@@ -364,15 +435,104 @@ struct WaveSel {
         __syncthreads();
         return first + (lnext < rlast ? lnext : rlast);
     }
-    __device__ int partition_pivot(int first, int last) {                 // __unguarded_partition_pivot
-        if (small != nullptr && last - first <= 64) return partition_pivot_small(first, last);
+    __device__ __forceinline__ static u64 bperm64(u64 v, int src_lane) {
+        const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)v);
+        const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)(v >> 32));
+        return ((u64)b << 32) | a;
+    }
+    __device__ __forceinline__ static u64 bits_below(int h) { return h >= 64 ? ~0ull : ((1ull << h) - 1); }
+    // __introsort_loop(first, last, d) of a range of at most 64 elements, one element per lane in a register until every
+    // run is <= 16 long.  The loop's recursion only ever splits a range in two and the halves never interact again, so
+    // all pending sub-ranges ("segments": lane intervals [sf, sl)) take their next __unguarded_partition_pivot in the SAME
+    // step — median-of-three through ds_bpermute, stopper sets as ballots masked to the lane's segment, the pairing by
+    // popcounts exactly as in partition_pivot_small — and every segment at step s has depth budget d - s, as in the
+    // serial recursion.  A segment that runs out of budget is left to the serial heap sort afterwards (libstdc++'s
+    // fallback), same moves as the scalar program.  A 64-element range costs 2-4 steps instead of 3-7 partitions.
+    __device__ __forceinline__ void sort64_body(int first, int last, int d) {
+        const int m = last - first;                                       // 17 .. 64
+        u64 x = lane < m ? arr[first + lane] : 0ull;
+        int sf = lane < m ? 0 : lane, sl = lane < m ? m : lane;           // lanes beyond the range: empty segments
+        bool done = false;
+        u64 bailed = 0;                                                   // first lanes of segments left to the heap sort
+        lds_int* const tl = small;                                            // positions by (segment start + rank), 2 x 65 ints
+        lds_int* const tr = small + 65;
+        const u64 self = 1ull << lane, below_incl = lane >= 63 ? ~0ull : ((2ull << lane) - 1);
+        const u64 above = lane >= 63 ? 0ull : (~0ull << (lane + 1));
+        while (true) {
+            bool active = !done && sl - sf > 16;
+            if (__ballot(active) == 0) break;
+            if (d == 0) {                                                 // every live segment is out of depth budget
+                bailed = __ballot(active && lane == sf);
+                break;
+            }
+            --d;
+            KVC_XCOUNT(8);
+            // __move_median_to_first(sf, sf + 1, mid, sl - 1)
+            const int ia = sf + 1, ib = sf + (sl - sf) / 2, ic = sl - 1;
+            const uint32_t ka = (uint32_t)__builtin_amdgcn_ds_bpermute((active ? ia : lane) << 2, (int)(uint32_t)(x >> 32));
+            const uint32_t kb = (uint32_t)__builtin_amdgcn_ds_bpermute((active ? ib : lane) << 2, (int)(uint32_t)(x >> 32));
+            const uint32_t kc = (uint32_t)__builtin_amdgcn_ds_bpermute((active ? ic : lane) << 2, (int)(uint32_t)(x >> 32));
+            int sw;
+            if (ka > kb) sw = kb > kc ? ib : (ka > kc ? ic : ia);
+            else sw = ka > kc ? ia : (kb > kc ? ic : ib);
+            const u64 v0 = bperm64(x, active ? sf : lane), vs = bperm64(x, active ? sw : lane);
+            if (active) x = lane == sf ? vs : (lane == sw ? v0 : x);
+            // __unguarded_partition(sf + 1, sl, pivot = sf)
+            const uint32_t pk = key(vs), kx = key(x);
+            const bool in = active && lane > sf;
+            const u64 segm = bits_below(sl) & ~bits_below(sf);
+            const u64 SL = __ballot(in && !(kx > pk)) & segm, SR = __ballot(in && !(pk > kx)) & segm;
+            const bool isl = in && (SL & self), isr = in && (SR & self);
+            const int t = __builtin_popcountll(SL & below_incl);          // rank among the segment's left stoppers, 1-based
+            const int u = __builtin_popcountll(SR & (above | self));      // rank among its right stoppers, 1-based from the right
+            const bool swl = isl && __builtin_popcountll(SR & above) >= t;
+            const bool swr = isr && __builtin_popcountll(SL & (below_incl >> 1)) >= u;
+            const int T = __builtin_popcountll(__ballot(swl) & segm);
+            if (isl) tl[sf + t] = lane;
+            if (isr) tr[sf + u] = lane;
+            __syncthreads();
+            const int partner = swl ? tr[sf + t] : (swr ? tl[sf + u] : lane);
+            const int NL = __builtin_popcountll(SL);
+            const int lnext = active && T < NL ? tl[sf + T + 1] : 0x7fffffff;
+            const int rlast = active && T > 0 ? tr[sf + T] : 0x7fffffff;
+            x = bperm64(x, partner);
+            __syncthreads();
+            if (active) {
+                const int cut = lnext < rlast ? lnext : rlast;
+                if (lane < cut) sl = cut; else sf = cut;
+            }
+        }
+        if (lane < m) arr[first + lane] = x;
+        __syncthreads();
+        Arr A{arr};
+        while (bailed) {                                                  // __partial_sort(f, l, l) = heap_select + sort_heap
+            const int b = __builtin_ctzll(bailed);
+            bailed &= bailed - 1;
+            const int f = first + __builtin_amdgcn_readlane(sf, b), l = first + __builtin_amdgcn_readlane(sl, b);
+            heap_select_(A, f, l, l);
+            sort_heap_(A, f, l);
+            __syncthreads();
+        }
+    }
+    // The three big pieces stay out of line (inlined at every call site they cost instruction cache and registers in the
+    // long scans), and take the view BY VALUE: a handful of pointers in registers.  As member functions they would get
+    // `this`, a pointer to the object in scratch memory, and reload every field through flat loads.
+    static __device__ __noinline__ int partition_pivot_small(WaveSel S, int first, int last) { return S.partition_pivot_small_body(first, last); }
+    static __device__ __noinline__ void sort64(WaveSel S, int first, int last, int d) { S.sort64_body(first, last, d); }
+    static __device__ __noinline__ int partition_pivot(WaveSel S, int first, int last) { return S.partition_pivot_body(first, last); }
+    __device__ __forceinline__ int partition_pivot_body(int first, int last) {   // __unguarded_partition_pivot
+        if (last - first <= 64) { KVC_XCOUNT(8); return partition_pivot_small(*this, first, last); }
+        KVC_XCOUNT(9);
         const int mid = first + (last - first) / 2;
         Arr A{arr};
+        KVC_XTIC(m0_);
         if (lane == 0) move_median_to_first_(A, first, first + 1, mid, last - 1);
         __syncthreads();
+        KVC_XTIC(m1_);
+        KVC_XACC(15, m0_, m1_);
         return partition(first + 1, last, first);
     }
-    __device__ void introselect(int first, int nth, int last, int depth_limit) {
+    __device__ __forceinline__ void introselect(int first, int nth, int last, int depth_limit) {
         Arr A{arr};
         while (last - first > 3) {
             if (depth_limit == 0) {
@@ -382,14 +542,39 @@ struct WaveSel {
                 return;
             }
             --depth_limit;
-            const int cut = partition_pivot(first, last);
+            const int cut = partition_pivot(*this, first, last);
             if (cut <= nth) first = cut; else last = cut;
         }
         insertion_sort_(A, first, last);
         __syncthreads();
     }
+    // __final_insertion_sort of [first, last) once every run left by the introsort loop is <= 16 long (see the header of
+    // this section): element i ends at i - #(j in [i-15, i): key_j < key_i) + #(j in (i, i+15]: key_j > key_i).  Elements
+    // below `lim` are placed; out[pos - first] is written when pos - first < want.  The 30 neighbour keys of a lane are
+    // requested in one go (clamped addresses, range tests on the counts): one LDS round trip per 64 elements.
+    __device__ __forceinline__ void final_place(int first, int last, int lim, int want, glb_i64* out) {
+        for (int base = first; base < lim; base += 64) {
+            const int i = base + lane, ic = i < last ? i : last - 1;
+            uint32_t kb[15], ka[15];
+#pragma unroll
+            for (int dlt = 1; dlt < 16; ++dlt) {
+                const int jb = ic - dlt, ja = ic + dlt;
+                kb[dlt - 1] = key(arr[jb >= first ? jb : first]);
+                ka[dlt - 1] = key(arr[ja < last ? ja : last - 1]);
+            }
+            const u64 v = arr[ic];
+            const uint32_t ki = key(v);
+            int pos = ic;
+#pragma unroll
+            for (int dlt = 1; dlt < 16; ++dlt) {
+                if (ic - dlt >= first && kb[dlt - 1] < ki) --pos;
+                if (ic + dlt < last && ka[dlt - 1] > ki) ++pos;
+            }
+            if (i < lim && pos - first < want) out[pos - first] = (int64_t)(v & 0xffffffffull);
+        }
+    }
     // std::sort(first, last) whose result goes straight to out[first..last) as indices
-    __device__ void sort_to(int first, int last, int* stack, int64_t* out) {
+    __device__ __forceinline__ void sort_to(int first, int last, lds_int* stack, glb_i64* out) {
         if (first == last) return;
         Arr A{arr};
         int sp = 0;
@@ -402,8 +587,9 @@ struct WaveSel {
                     __syncthreads();
                     break;
                 }
+                if (l - f <= 64) { sort64(*this, f, l, d); break; }           // the whole subtree, in registers
                 --d;
-                const int cut = partition_pivot(f, l);
+                const int cut = partition_pivot(*this, f, l);
                 if (lane == 0) { stack[3 * sp] = cut; stack[3 * sp + 1] = l; stack[3 * sp + 2] = d; }
                 ++sp;
                 l = cut;
@@ -414,21 +600,8 @@ struct WaveSel {
             f = uni(stack[3 * sp]); l = uni(stack[3 * sp + 1]); d = uni(stack[3 * sp + 2]);
         }
         __syncthreads();
-        for (int base = first; base < last; base += 64) {                  // __final_insertion_sort, all elements at once
-            const int i = base + lane;
-            if (i < last) {
-                const u64 v = arr[i];
-                const uint32_t ki = key(v);
-                int pos = i;
-#pragma unroll 5
-                for (int dlt = 1; dlt < 16; ++dlt) {
-                    const int jb = i - dlt, ja = i + dlt;
-                    if (jb >= first && key(arr[jb]) < ki) --pos;
-                    if (ja < last && key(arr[ja]) > ki) ++pos;
-                }
-                out[pos] = (int64_t)(v & 0xffffffffull);
-            }
-        }
+        KVC_XSTAMP(3);
+        final_place(first, last, last, last - first, out + first);        // __final_insertion_sort, all elements at once
     }
     // (caps == nullptr in the kernel below: the whole sort.)
     // The first `want` elements of std::sort(first, last), written to out[0..want) as indices (AdaKV / HeadKV keep a prefix of
@@ -437,7 +610,7 @@ struct WaveSel {
     // behind every element to its left, it is never mixed with them again, and the final insertion sort moves an element
     // by at most 15 places inside its own leaf range.  So: partition exactly as libstdc++ does, descend only into ranges
     // that start before `want`, then place the elements below want + 16 by the stable-insertion count of sort_to().
-    __device__ void sort_prefix_to(int first, int last, int want, int* stack, int64_t* out) {
+    __device__ __forceinline__ void sort_prefix_to(int first, int last, int want, lds_int* stack, glb_i64* out) {
         if (first == last || want <= 0) return;
         Arr A{arr};
         int sp = 0;
@@ -450,8 +623,9 @@ struct WaveSel {
                     __syncthreads();
                     break;
                 }
+                if (l - f <= 64) { sort64(*this, f, l, d); break; }
                 --d;
-                const int cut = partition_pivot(f, l);
+                const int cut = partition_pivot(*this, f, l);
                 if (cut < first + want) {                                  // the right part still reaches into the prefix
                     if (lane == 0) { stack[3 * sp] = cut; stack[3 * sp + 1] = l; stack[3 * sp + 2] = d; }
                     ++sp;
@@ -465,21 +639,7 @@ struct WaveSel {
         }
         __syncthreads();
         const int lim = first + want + 16 < last ? first + want + 16 : last;
-        for (int base = first; base < lim; base += 64) {
-            const int i = base + lane;
-            if (i < lim) {
-                const u64 v = arr[i];
-                const uint32_t ki = key(v);
-                int pos = i;
-#pragma unroll 5
-                for (int dlt = 1; dlt < 16; ++dlt) {
-                    const int jb = i - dlt, ja = i + dlt;
-                    if (jb >= first && key(arr[jb]) < ki) --pos;
-                    if (ja < last && key(arr[ja]) > ki) ++pos;
-                }
-                if (pos - first < want) out[pos - first] = (int64_t)(v & 0xffffffffull);
-            }
-        }
+        final_place(first, last, lim, want, out);
     }
 };
 
@@ -706,7 +866,8 @@ constexpr size_t kWaveHeapLds = (192 + 128) * 8;
 // grid = (heads, items), block = 64 (one wave).  LDS: introsort stack + array (or heap).
 // ---------------------------------------------------------------------------------------------------------
 template <int DT>
-__global__ __launch_bounds__(64) void select_exact_kernel(const SelectArgs a, u64* gscratch /*[heads][n] or null*/, int arr_in_lds) {
+__global__ __launch_bounds__(64) void select_exact_kernel(const SelectArgs a, u64* gscratch /*[heads][n] or null*/, int arr_in_lds,
+                                                           int list_bytes /*LDS behind the array / sort region*/) {
     typedef typename Dt<DT>::raw raw;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* stack = reinterpret_cast<int*>(smem);                        // 3 * 96 ints
@@ -764,33 +925,94 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const SelectArgs a, u6
         for (int t = lane; t < k; t += 64) out[t] = (int64_t)(lds_arr[t] & 0xffffffffull);
     } else {
         // scratch per (item, head): [n u64 array, when it does not fit in LDS][2 x (n/2 + 2) int position lists]
-        const bool small_lists = (arr_in_lds & 2) != 0;
-        arr_in_lds &= 1;
         const int64_t per_head = (arr_in_lds ? 0 : (int64_t)n) + (n / 2 + 2);
         u64* const hs = gscratch + ((int64_t)item * a.heads + head) * per_head;
-        u64* arr = arr_in_lds ? lds_arr : hs;
-        int* const lists = reinterpret_cast<int*>(hs + (arr_in_lds ? 0 : n));
-        // LDS behind the array region (n elements, or the k_max - 1 being sorted): lists for small partitions
-        int* const small = small_lists ? reinterpret_cast<int*>(lds_arr + (arr_in_lds ? n : a.k_max)) : nullptr;
-        for (int i = lane; i < n; i += 64) arr[i] = ((u64)Key<DT>::of(s[i]) << 32) | (uint32_t)i;
-        __syncthreads();
-        WaveSel S{arr, lists, lists + (n / 2 + 2), small, lane};
-        // std::nth_element(first, first + k - 1, last)
-        if (k - 1 != n) S.introselect(0, k - 1, n, lg_(n) * 2);
-        // std::sort(first, first + k - 1), written to out as it is placed; the nth element follows.  When the array lives
-        // in the workspace the k - 1 leading elements move to LDS first: the sort makes hundreds of small partitions, each
-        // a handful of dependent accesses — a memory round trip apiece on the workspace copy.
-        const u64 nth = arr[k - 1];
-        if (!arr_in_lds && k - 1 > 0) {
-            for (int i = lane; i < k - 1; i += 64) lds_arr[i] = arr[i];
+        glb_int* const lists = (glb_int*)(hs + (arr_in_lds ? 0 : n));
+        lds_u64* const larr = (lds_u64*)lds_arr;
+        lds_int* const lstack = (lds_int*)stack;
+        glb_i64* const gout = (glb_i64*)out;
+        // LDS list region: behind the array (n elements), or behind the k_max - 1 elements being sorted — and while
+        // nth_element runs on the workspace copy, that sort region is free too: its lists start at lds_arr
+        lds_int* const small = (lds_int*)(larr + (arr_in_lds ? n : a.k_max));
+#if defined(KVC_STAMPS)
+        unsigned long long xstamps_[20] = {}, xsa[20] = {}, xsb[20] = {};
+#endif
+        u64 nth;
+        if (arr_in_lds) {
+            for (int i = lane; i < n; i += 64) larr[i] = ((u64)Key<DT>::of(s[i]) << 32) | (uint32_t)i;
             __syncthreads();
-            WaveSel S2{lds_arr, lists, lists + (n / 2 + 2), small, lane};
-            S2.sort_to(0, k - 1, stack, out);
+            WaveSel<lds_u64> S{larr, lists, lists + (n / 2 + 2), small, lane};
+            S.small_bytes = list_bytes;
+#if defined(KVC_STAMPS)
+            S.xstamps_ = xsa;
+#endif
+            KVC_XSTAMP(0);
+            if (k - 1 != n) S.introselect(0, k - 1, n, lg_(n) * 2);          // std::nth_element(first, first + k - 1, last)
+#if defined(KVC_STAMPS)
+            xstamps_[10] = xsa[8]; xstamps_[11] = xsa[9];
+            for (int i = 0; i < 4; ++i) xstamps_[16 + i] = xsa[12 + i];
+#endif
+            KVC_XSTAMP(1);
+            nth = larr[k - 1];
+            KVC_XSTAMP(2);
+            S.sort_to(0, k - 1, lstack, gout);                               // std::sort(first, first + k - 1), straight to out
+#if defined(KVC_STAMPS)
+            xstamps_[3] = xsa[3]; xstamps_[8] = xsa[8]; xstamps_[9] = xsa[9];
+            for (int i = 12; i < 16; ++i) xstamps_[i] = xsa[i];
+#endif
         } else {
-            S.sort_to(0, k - 1, stack, out);
+            glb_u64* const garr = (glb_u64*)hs;
+            for (int i = lane; i < n; i += 64) garr[i] = ((u64)Key<DT>::of(s[i]) << 32) | (uint32_t)i;
+            __syncthreads();
+            WaveSel<glb_u64> S{garr, lists, lists + (n / 2 + 2), (lds_int*)larr, lane};
+            S.small_bytes = list_bytes + a.k_max * 8;
+#if defined(KVC_STAMPS)
+            S.xstamps_ = xsa;
+#endif
+            KVC_XSTAMP(0);
+            if (k - 1 != n) S.introselect(0, k - 1, n, lg_(n) * 2);
+#if defined(KVC_STAMPS)
+            xstamps_[10] = xsa[8]; xstamps_[11] = xsa[9];
+            for (int i = 0; i < 4; ++i) xstamps_[16 + i] = xsa[12 + i];
+#endif
+            KVC_XSTAMP(1);
+            // The k - 1 leading elements move to LDS for the sort: it makes hundreds of small partitions, each a handful of
+            // dependent accesses — a memory round trip apiece on the workspace copy.
+            nth = garr[k - 1];
+            for (int i = lane; i < k - 1; i += 64) larr[i] = garr[i];
+            __syncthreads();
+            WaveSel<lds_u64> S2{larr, lists, lists + (n / 2 + 2), small, lane};
+            S2.small_bytes = list_bytes;
+#if defined(KVC_STAMPS)
+            S2.xstamps_ = xsb;
+#endif
+            KVC_XSTAMP(2);
+            S2.sort_to(0, k - 1, lstack, gout);
+#if defined(KVC_STAMPS)
+            xstamps_[3] = xsb[3]; xstamps_[8] = xsa[8] + xsb[8]; xstamps_[9] = xsa[9] + xsb[9];
+            for (int i = 12; i < 16; ++i) xstamps_[i] = xsa[i] + xsb[i];
+#endif
         }
         if (lane == 0) out[k - 1] = (int64_t)(nth & 0xffffffffull);
+#if defined(KVC_STAMPS)
+        KVC_XSTAMP(4);
+        __syncthreads();
+        if (lane == 0 && a.fuse == 2 && k >= 20) for (int i = 0; i < 20; ++i) out[i] = (int64_t)xstamps_[i];
+#endif
     }
+}
+
+// LDS list region behind `fixed` bytes of a workgroup: what the lists of an n-element range need, cut back to what keeps
+// as many workgroups resident per CU as the minimal region would (160 KB per CU, counted in 1280-byte granules).
+static size_t list_region_bytes(size_t fixed, int n) {
+    const size_t cu = 160 * 1024, gran = 1280, full = (list_bytes_for(n < 65536 ? n : 65536) + 15) & ~(size_t)15;
+    size_t wgs = cu / ((fixed + kMinListBytes + gran - 1) / gran * gran);
+    if (wgs < 1) wgs = 1;
+    if (wgs > 32) wgs = 32;
+    size_t room = cu / wgs / gran * gran;
+    room = room > fixed ? (room - fixed) & ~(size_t)15 : 0;
+    size_t bytes = full < room ? full : room;
+    return bytes < kMinListBytes ? kMinListBytes : bytes;
 }
 
 size_t select_exact_scratch_bytes(int heads, int n, int k) {
@@ -806,20 +1028,19 @@ static int launch_exact_t(const SelectArgs& a, void* scratch, hipStream_t st) {
     for (int i = 0; i < a.n_items; ++i) any_nth = any_nth || !((int64_t)a.k.v[i] * 64 <= (int64_t)a.n);
     const int in_lds = !any_nth || a.n <= 18000;
     // LDS: the whole array (nth_element items, n <= 18000), or the heap of k_max (partial_sort) / the k_max - 1 elements
-    // being sorted; plus 4 KB of lists for small partitions — unless that costs a resident wave per CU (160 KB of LDS, one
-    // wave = one workgroup here: these kernels are latency-bound, a second round of workgroups doubles their time)
+    // being sorted; behind it the list region of the partitions, as large as the resident workgroups per CU allow (160 KB
+    // of LDS, one wave = one workgroup here: these kernels are latency-bound, a second round of workgroups doubles
+    // their time) up to what the longest range needs
     size_t body = (in_lds && any_nth) ? (size_t)a.n * 8 : (size_t)a.k_max * 8;
     if (body < kWaveHeap9Lds) body = kWaveHeap9Lds;
     if (body < kWaveHeapLds) body = kWaveHeapLds;                   // 64-bit nodes (fp32, or n > 65536)
-    const bool small_lists = any_nth && (160 * 1024) / (1152 + body + kSmallListBytes) == (160 * 1024) / (1152 + body) &&
-                             1152 + body + kSmallListBytes <= 150 * 1024;
-    if (small_lists) body += kSmallListBytes;
-    const size_t lds = 1152 + body;
+    const size_t list_bytes = any_nth ? list_region_bytes(1152 + body, a.n) : 0;
+    const size_t lds = 1152 + body + list_bytes;
     if (any_nth && !scratch) return KVC_ERR_WORKSPACE;
     static LdsCache lds_cache = {};
     if (ensure_lds(reinterpret_cast<const void*>(&select_exact_kernel<DT>), lds, lds_cache) != 0) return KVC_ERR_HIP;
     hipLaunchKernelGGL((select_exact_kernel<DT>), dim3((unsigned)a.heads, (unsigned)a.n_items), dim3(64), lds, st, a,
-                       reinterpret_cast<u64*>(scratch), in_lds | (small_lists ? 2 : 0));
+                       reinterpret_cast<u64*>(scratch), in_lds, (int)list_bytes);
     return 0;
 }
 
@@ -829,7 +1050,7 @@ static int launch_exact_t(const SelectArgs& a, void* scratch, hipStream_t st) {
 // grid = (heads), block = 64.  The (key, index) array lives in LDS (n <= 18000) or in `gscratch` ([heads][n] u64).
 // ---------------------------------------------------------------------------------------------------------
 template <int DT>
-__global__ __launch_bounds__(64) void sort_prefix_kernel(const RaggedSortArgs a, u64* gscratch, int arr_in_lds) {
+__global__ __launch_bounds__(64) void sort_prefix_kernel(const RaggedSortArgs a, u64* gscratch, int arr_in_lds, int list_bytes) {
     typedef typename Dt<DT>::raw raw;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* stack = reinterpret_cast<int*>(smem);                        // 3 * 96 ints
@@ -841,13 +1062,30 @@ __global__ __launch_bounds__(64) void sort_prefix_kernel(const RaggedSortArgs a,
     int64_t* out = a.idx_out + (int64_t)head * a.out_stride;
     const int64_t per_head = (arr_in_lds ? 0 : (int64_t)n) + (n / 2 + 2);
     u64* const hs = gscratch + (int64_t)head * per_head;
-    u64* arr = arr_in_lds ? lds_arr : hs;
-    int* const lists = reinterpret_cast<int*>(hs + (arr_in_lds ? 0 : n));
-    int* const small = arr_in_lds ? reinterpret_cast<int*>(lds_arr + n) : reinterpret_cast<int*>(lds_arr);
-    for (int i = lane; i < n; i += 64) arr[i] = ((u64)Key<DT>::of(s[i]) << 32) | (uint32_t)i;
-    __syncthreads();
-    WaveSel S{arr, lists, lists + (n / 2 + 2), small, lane};
-    S.sort_prefix_to(0, n, want, stack, out);
+    glb_int* const lists = (glb_int*)(hs + (arr_in_lds ? 0 : n));
+    lds_u64* const larr = (lds_u64*)lds_arr;
+    if (arr_in_lds) {
+        for (int i = lane; i < n; i += 64) larr[i] = ((u64)Key<DT>::of(s[i]) << 32) | (uint32_t)i;
+        __syncthreads();
+        WaveSel<lds_u64> S{larr, lists, lists + (n / 2 + 2), (lds_int*)(larr + n), lane};
+        S.small_bytes = list_bytes;
+#if defined(KVC_STAMPS)
+        unsigned long long xs[20] = {};
+        S.xstamps_ = xs;
+#endif
+        S.sort_prefix_to(0, n, want, (lds_int*)stack, (glb_i64*)out);
+    } else {
+        glb_u64* const garr = (glb_u64*)hs;
+        for (int i = lane; i < n; i += 64) garr[i] = ((u64)Key<DT>::of(s[i]) << 32) | (uint32_t)i;
+        __syncthreads();
+        WaveSel<glb_u64> S{garr, lists, lists + (n / 2 + 2), (lds_int*)larr, lane};
+        S.small_bytes = list_bytes;
+#if defined(KVC_STAMPS)
+        unsigned long long xs[20] = {};
+        S.xstamps_ = xs;
+#endif
+        S.sort_prefix_to(0, n, want, (lds_int*)stack, (glb_i64*)out);
+    }
 }
 
 size_t sort_prefix_scratch_bytes(int heads, int n) {
@@ -857,11 +1095,17 @@ size_t sort_prefix_scratch_bytes(int heads, int n) {
 template <int DT>
 static int launch_sort_prefix_t(const RaggedSortArgs& a, void* scratch, hipStream_t st) {
     const int in_lds = a.n <= 18000;
-    const size_t lds = 1152 + (in_lds ? (size_t)a.n * 8 : 0) + kSmallListBytes;
+    // a handful of workgroups (one per head): the lists of the whole range in LDS when the array leaves room for them
+    const size_t fixed = 1152 + (in_lds ? (size_t)a.n * 8 : 0);
+    size_t list_bytes = (list_bytes_for(a.n < 65536 ? a.n : 65536) + 15) & ~(size_t)15;
+    if (fixed + list_bytes > 160 * 1024) list_bytes = (160 * 1024 - fixed) & ~(size_t)15;
+    if (list_bytes < kMinListBytes) list_bytes = kMinListBytes;
+    const size_t lds = fixed + list_bytes;
     if (!scratch) return KVC_ERR_WORKSPACE;
     static LdsCache lds_cache = {};
     if (ensure_lds(reinterpret_cast<const void*>(&sort_prefix_kernel<DT>), lds, lds_cache) != 0) return KVC_ERR_HIP;
-    hipLaunchKernelGGL((sort_prefix_kernel<DT>), dim3((unsigned)a.heads), dim3(64), lds, st, a, reinterpret_cast<u64*>(scratch), in_lds);
+    hipLaunchKernelGGL((sort_prefix_kernel<DT>), dim3((unsigned)a.heads), dim3(64), lds, st, a, reinterpret_cast<u64*>(scratch), in_lds,
+                       (int)list_bytes);
     return 0;
 }
 

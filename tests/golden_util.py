@@ -70,3 +70,20 @@ def product_modes(oracle, meta):
     """The oracle arithmetic that mirrors the GPU product: fmaf-chain dot products (what the gfx950 f32-input MFMA
     computes) and softmax row sums in torch's own 16-lane order (kvc_score.hip torch16_rowsums, kvc_h2o.hip)."""
     return dict(dot_mode=oracle.DOT_CHAIN, sum_mode=oracle.SUM_TORCH16)
+
+
+KILLERS = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("killer_") and f.endswith(".npz"))
+
+
+def killer(name, dtype):
+    """An adversarial score row (oracle/killer_adversary.h, tests/golden/killer_*.npz) in `dtype`, its budget k and the indices
+    torch-CPU topk returned for it when the fixture was made.  Codes become fp32 integers, or consecutive positive normal
+    bf16 / fp16 bit patterns: the order and the ties of the codes carry over exactly."""
+    a = arrays(name)
+    codes = torch.from_numpy(a["codes"].astype(np.int64))
+    if dtype == torch.float32:
+        sc = codes.float()
+    else:
+        assert int(codes.max()) + 0x0480 < 0x7800, "row too long for consecutive 16-bit codes"
+        sc = (codes + 0x0480).to(torch.int16).view(dtype)
+    return sc[None].contiguous(), int(a["k"]), torch.from_numpy(a["want"])[None]

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../kvcache_factory_amd/csrc/kvc_stl_emul.h"
+#include "../oracle/killer_adversary.h"
 
 using kvc::u64;
 typedef std::pair<float, int64_t> elem;
@@ -112,6 +113,34 @@ int main(int argc, char** argv) {
         for (int i = 0; i < want; ++i)
             if (out[i] != q[i].second) { printf("SORT-PREFIX MISMATCH trial %d n=%d want=%d at %d: real %ld emul %ld\n", t, n, want, i, (long)q[i].second, (long)out[i]); return 1; }
         checked += want;
+    }
+    // Adversarial rows (oracle/killer_adversary.h): every partition degenerate, the depth budgets of introselect and of
+    // introsort run out and the heap fallbacks of the emulation run
+    const int kn[][2] = {{2000, 60}, {600, 100}, {1000, 999}, {1000, 1000}, {7992, 234}, {7992, 2040}, {20000, 400}, {64, 64}, {300, 40}};
+    for (const auto& c : kn) {
+        const std::vector<int> codes = killer::topk_scores(c[0], c[1]);
+        std::vector<float> v(codes.begin(), codes.end());
+        const auto a = real_topk(v, c[1]), b = emul_topk(v, c[1]);
+        for (int i = 0; i < c[1]; ++i)
+            if (a[i] != b[i]) { printf("KILLER MISMATCH n=%d k=%d at %d: real %ld emul %ld\n", c[0], c[1], i, (long)a[i], (long)b[i]); return 1; }
+        checked += c[1];
+    }
+    for (int n : {64, 65, 600, 4000, 7992}) {
+        const std::vector<int> codes = killer::sort_scores(n);
+        std::vector<elem> q(n);
+        for (int i = 0; i < n; ++i) q[i] = elem((float)codes[i], i);
+        std::sort(q.begin(), q.end(), [](const elem& x, const elem& y) { return x.first > y.first; });
+        for (int want : {n, n / 3 + 1, 17}) {
+            std::vector<u64> arr(n);
+            for (int i = 0; i < n; ++i) arr[i] = ((u64)key_of((float)codes[i]) << 32) | (uint32_t)i;
+            kvc::Arr A{arr.data()};
+            std::vector<int> stack(3 * 96);
+            std::vector<int64_t> out(want, -1);
+            kvc::sort_prefix_(A, 0, n, want, stack.data(), out.data());
+            for (int i = 0; i < want; ++i)
+                if (out[i] != q[i].second) { printf("KILLER SORT-PREFIX MISMATCH n=%d want=%d at %d\n", n, want, i); return 1; }
+            checked += want;
+        }
     }
     printf("OK %d trials, %ld indices identical to libstdc++\n", trials, checked);
     return 0;

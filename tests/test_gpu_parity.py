@@ -972,3 +972,31 @@ def test_compress_at_128k_context(kvc, oracle, gpu_device):
                                          sum_mode=oracle.SUM_TORCH16, tie_mode=oracle.TIES_TORCH)
     assert torch.equal(G.bits(sc[0]), G.bits(sc_)) and torch.equal(idx[0].cpu(), io_)
     assert torch.equal(G.bits(ko), G.bits(ko_)) and torch.equal(G.bits(vo), G.bits(vo_))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("name", G.KILLERS)
+def test_exact_ties_on_adversarial_rows(kvc, oracle, gpu_device, name, dtype):
+    """tie_mode torch_cpu on rows that make every median-of-three partition degenerate (McIlroy's adversary run against the
+    real libstdc++, oracle/killer_adversary.h): nth_element spends its 2 lg(n) depth budget and finishes by heap select,
+    the sort of the leaders spends its own — inside the in-register sort of <= 64-element ranges too — and finishes by heap
+    sort.  Indices must equal torch-CPU topk's (stored in the fixture) and the oracle's, order included."""
+    sc, k, want = G.killer(name, dtype)
+    assert torch.equal(oracle.topk(sc, k, oracle.TIES_TORCH)[0], want)
+    got = kvc.select(sc[None].to(gpu_device), k, "torch_cpu")[0].cpu()
+    assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k", [(8192, 100), (8192, 128), (32768, 300), (32768, 512), (20000, 313), (7992, 2040)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_exact_ties_on_rising_scores(kvc, oracle, gpu_device, n, k, dtype):
+    """Scores that rise with the position: in the partial_sort regime EVERY candidate beats the heap's root (n - k
+    __adjust_heap steps, the longest chain heap_select can be made to run); in the nth_element regime the median-of-three
+    sees a sorted row.  Two heads: strictly rising (fp32) / rising plateaus (bf16 rounds neighbours together), and falling."""
+    ramp = torch.arange(n, dtype=torch.float32) / n + 1.0
+    sc = torch.stack([ramp, ramp.flip(0)]).to(dtype).contiguous()
+    want, _ = oracle.topk(sc, k, oracle.TIES_TORCH)
+    got = kvc.select(sc[None].to(gpu_device), k, "torch_cpu")[0].cpu()
+    assert torch.equal(got, want)

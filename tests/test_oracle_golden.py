@@ -156,3 +156,15 @@ def test_adakv_headkv_against_reference(oracle, name):
     ref_sc = G.from_bits(arr["scores"], G.DT[m["dtype"]])
     d = G.ulp_diff(sc, ref_sc)
     assert int(d.max()) <= (32 if m["dtype"] == "fp32" else 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("name", G.KILLERS)
+def test_topk_on_adversarial_rows(oracle, name, dtype):
+    """Rows built by McIlroy's adversary against the real libstdc++ nth_element + sort (oracle/killer_adversary.h): every
+    partition is degenerate, introselect / introsort spend their depth budget and fall back to heap select / heap sort.
+    The oracle must return what torch-CPU topk returned when the fixture was generated, and what it returns here."""
+    sc, k, want = G.killer(name, dtype)
+    got, _ = oracle.topk(sc, k, oracle.TIES_TORCH)
+    assert torch.equal(got, want)
+    assert torch.equal(torch.topk(sc.float(), k, dim=-1).indices, want)
