@@ -50,7 +50,9 @@ typedef enum kvc_method {      /* which update_kv is being replaced */
     KVC_STREAMINGLLM = 3,      /* :595-620 — no scoring: first k + last window tokens */
     KVC_ADAKV = 4,             /* :622-757 — window-MEAN scores, per-head budgets from a global top-(H*base), ragged cache:
                                   kvc_ragged_* entry points only (k = base capacity = max_capacity_prompt - W) */
-    KVC_HEADKV = 5             /* :760-878 — the same with per-head budgets given by the caller */
+    KVC_HEADKV = 5,            /* :760-878 — the same with per-head budgets given by the caller */
+    KVC_L2NORM = 6             /* :394-429 — L2NormCluster: the k smallest-norm keys per head, ascending; no query, no window:
+                                  kvc_l2norm_* entry points only (k = rows kept = max_capacity_prompt) */
 } kvc_method;
 
 typedef enum kvc_dtype { KVC_BF16 = 0, KVC_FP16 = 1, KVC_FP32 = 2 } kvc_dtype;
@@ -233,6 +235,22 @@ typedef struct kvc_ragged_decode_params {
 } kvc_ragged_decode_params;
 int kvc_ragged_decode_step(const kvc_ragged_decode_params* p, const void* q, const void* k_new, const void* v_new,
                            void* k_flat, void* v_flat, const int64_t* seg_off, const int32_t* seg_len, void* out, void* hip_stream);
+
+/* ---- L2NormCluster.update_kv (pyramidkv_utils.py:394-429) ------------------------------------------
+ * The k = max_capacity_prompt keys of every head with the SMALLEST L2 norm, in ascending norm order, and their values:
+ *   token_norms = torch.norm(key_states, p=2, dim=-1)  (:419)  -> argsort ascending (:420) -> gather, first k rows (:423-427).
+ * p->method = KVC_L2NORM; p->k = rows kept (1 <= k <= q_len); window, kernel_size, pooling, tie_mode, dot_mode and the q
+ * strides are ignored (the reference's cluster takes neither a query nor a window).  The caller decides pass-through
+ * (q_len < max_capacity_prompt, or layer_idx in skip_layers: :413-416) and does not call.
+ * Norm arithmetic = torch-CPU's (8 fp32 accumulators by d % 8, added 0..7, fp32 sqrt, one rounding to the dtype);
+ * order of equal norms = torch-CPU's sort (libstdc++ std::sort on (value, index), ascending).
+ * k, v: [b][n_kv_heads][L][D] by the k_/v_ strides; k_out, v_out: [b][n_q_heads][k][D] (p->out_stride_h elements between
+ * heads, 0 = dense) — query heads of one KV group receive identical rows, as the reference's expanded tensors do.
+ * idx_out [b*n_q_heads][k] int64 and norms_out [b][n_q_heads][L] dtype may be NULL.
+ * Workspace: kvc_l2norm_workspace_bytes(p), 256-byte aligned. */
+size_t kvc_l2norm_workspace_bytes(const kvc_params* p);
+int kvc_l2norm_compress(const kvc_params* p, const void* k, const void* v, void* k_out, void* v_out, int64_t* idx_out,
+                        void* norms_out, void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* Debug/parity aid: byte offsets inside the workspace of the intermediates kvc_scores leaves behind.
  * offs[0]=logits [b][h][L][W] dtype, offs[1]=row max [b][h][W] f32, offs[2]=row sum [b][h][W] f32.

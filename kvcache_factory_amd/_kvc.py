@@ -8,7 +8,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KVC_LIB_PATH", os.path.join(_HERE, "libkvc_hip.so"))   # override only for diagnostic builds
 
-SNAPKV, PYRAMIDKV, H2O, STREAMINGLLM, ADAKV, HEADKV = 0, 1, 2, 3, 4, 5
+SNAPKV, PYRAMIDKV, H2O, STREAMINGLLM, ADAKV, HEADKV, L2NORM = 0, 1, 2, 3, 4, 5, 6
 BF16, FP16, FP32 = 0, 1, 2
 POOL_NONE, POOL_AVG, POOL_MAX = 0, 1, 2
 TIES_TORCH_CPU, TIES_CANONICAL = 0, 1
@@ -24,7 +24,7 @@ DOT_MODE = os.environ.get("KVC_DOT_MODE", "exact")      # default of every helpe
 EXPORTS = ("kvc_version", "kvc_last_error", "kvc_workspace_bytes", "kvc_compress", "kvc_scores", "kvc_select",
            "kvc_gather", "kvc_pyramid_k", "kvc_workspace_layout", "kvc_workspace_bytes_batch", "kvc_compress_batch",
            "kvc_select_workspace_bytes", "kvc_decode_step", "kvc_ragged_workspace_bytes", "kvc_ragged_plan",
-           "kvc_ragged_compact", "kvc_ragged_decode_step")
+           "kvc_ragged_compact", "kvc_ragged_decode_step", "kvc_l2norm_workspace_bytes", "kvc_l2norm_compress")
 
 
 class KvcError(RuntimeError):
@@ -92,6 +92,9 @@ def lib():
         L.kvc_ragged_decode_step.argtypes = [ctypes.POINTER(RaggedDecodeParams)] + [vp] * 9
         L.kvc_select_workspace_bytes.argtypes = [pp]
         L.kvc_select_workspace_bytes.restype = sz
+        L.kvc_l2norm_workspace_bytes.argtypes = [pp]
+        L.kvc_l2norm_workspace_bytes.restype = sz
+        L.kvc_l2norm_compress.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         _lib = L
     return _lib
 
@@ -384,6 +387,34 @@ def ragged_decode_step(q, k_new, v_new, k_flat, v_flat, seg_off, seg_len, append
     _check(_call(dev, lib().kvc_ragged_decode_step, ctypes.byref(p), _ptr(q), _ptr(k_new), _ptr(v_new), _ptr(k_flat), _ptr(v_flat),
                  _ptr(seg_off), _ptr(seg_len), _ptr(out), _stream(dev)))
     return out
+
+
+def l2norm_compress(k, v, rows, n_q_heads=None, return_indices=False, return_norms=False, out=None):
+    """L2NormCluster.update_kv's kept branch (pyramidkv_utils.py:418-429) on the GPU (kvc_l2norm_compress): the `rows` keys of
+    every head with the smallest L2 norm, ascending, and their values.  k, v: [b, H_kv (or H_q), L, D]; returns
+    (k_out [b, H_q, rows, D], v_out[, idx int64 [b, H_q, rows]][, norms [b, H_q, L]])."""
+    _require_gpu(k, v)
+    k, v = _last_dim_contig(k), _last_dim_contig(v)
+    dev = _one_device(k, v, *(out if out is not None else ()))
+    hq = n_q_heads if n_q_heads is not None else k.shape[1]
+    p = make_params(L2NORM, None, k, v, 0, rows, 1, None)
+    p.n_q_heads = hq
+    bsz, L, D = k.shape[0], k.shape[2], k.shape[3]
+    k_out, v_out, p.out_stride_h = _out_views(out, bsz, hq, rows, D, k.dtype, dev)
+    idx = torch.empty(bsz, hq, rows, dtype=torch.int64, device=dev) if return_indices else None
+    norms = torch.empty(bsz, hq, L, dtype=k.dtype, device=dev) if return_norms else None
+    nbytes = lib().kvc_l2norm_workspace_bytes(ctypes.byref(p))
+    if nbytes == 0:
+        raise KvcError(ERR_INVALID, lib().kvc_last_error().decode())
+    ws = workspace(dev, nbytes)
+    _check(_call(dev, lib().kvc_l2norm_compress, ctypes.byref(p), _ptr(k), _ptr(v), _ptr(k_out), _ptr(v_out), _ptr(idx), _ptr(norms),
+                 _ptr(ws), nbytes, _stream(dev)))
+    res = [k_out[:, :, :rows], v_out[:, :, :rows]]
+    if return_indices:
+        res.append(idx)
+    if return_norms:
+        res.append(norms)
+    return tuple(res)
 
 
 def pyramid_k(cap, window, q_len, layer_idx, n_layers, beta=20):

@@ -32,6 +32,7 @@ _INIT = {
     "snapkv": pu.init_snapkv,
     "h2o": pu.init_H2O,
     "streamingllm": pu.init_StreamingLLM,
+    "l2norm": pu.init_l2norm,
 }
 
 

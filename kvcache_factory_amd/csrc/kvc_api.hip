@@ -632,6 +632,86 @@ __attribute__((visibility("default"))) int kvc_ragged_compact(const kvc_params* 
     return hip_ok("ragged compact launch");
 }
 
+// ---- L2NormCluster.update_kv (pyramidkv_utils.py:394-429) ---------------------------------------------
+namespace {
+struct L2Layout { size_t norms, idx, sort, total; };
+L2Layout l2norm_carve(const kvc_params* p) {
+    L2Layout l;
+    const size_t heads = (size_t)p->bsz * p->n_q_heads, L = (size_t)p->q_len;
+    size_t off = 0;
+    l.norms = off; off = align_up(off + heads * L * esize_of(p->dtype), 256);
+    l.idx = off;   off = align_up(off + heads * (size_t)p->k * 8, 256);
+    l.sort = off;  off = align_up(off + kvc::sort_prefix_scratch_bytes((int)heads, (int)L), 256);
+    l.total = off;
+    return l;
+}
+int l2norm_check(const kvc_params* p) {
+    if (!p) return fail(KVC_ERR_INVALID, "params is NULL");
+    if (p->method != KVC_L2NORM) return fail(KVC_ERR_INVALID, "kvc_l2norm_*: method must be KVC_L2NORM");
+    if (p->dtype < KVC_BF16 || p->dtype > KVC_FP32) return fail(KVC_ERR_INVALID, "unknown dtype %d", p->dtype);
+    if (p->bsz < 1 || p->n_q_heads < 1 || p->n_kv_heads < 1) return fail(KVC_ERR_INVALID, "bsz / head counts must be positive");
+    if (p->n_q_heads % p->n_kv_heads) return fail(KVC_ERR_INVALID, "n_q_heads %d not a multiple of n_kv_heads %d", p->n_q_heads, p->n_kv_heads);
+    if (p->q_len < 1) return fail(KVC_ERR_INVALID, "q_len must be positive");
+    if (p->k < 1 || p->k > p->q_len) return fail(KVC_ERR_INVALID, "k=%d outside [1, q_len=%d] (rows kept = max_capacity_prompt)", p->k, p->q_len);
+    const int es = esize_of(p->dtype);
+    if (p->head_dim < 1 || (p->head_dim * es) % 32) return fail(KVC_ERR_UNSUPPORTED, "head_dim*esize must be a multiple of 32 bytes");
+    if (p->head_dim * es > 4096) return fail(KVC_ERR_UNSUPPORTED, "head_dim too large");
+    return KVC_OK;
+}
+}  // namespace
+
+__attribute__((visibility("default"))) size_t kvc_l2norm_workspace_bytes(const kvc_params* p) {
+    if (l2norm_check(p) != KVC_OK) return 0;
+    g_err[0] = 0;
+    return l2norm_carve(p).total;
+}
+
+__attribute__((visibility("default"))) int kvc_l2norm_compress(const kvc_params* p, const void* k, const void* v, void* k_out, void* v_out,
+                                                               int64_t* idx_out, void* norms_out, void* workspace, size_t workspace_bytes,
+                                                               void* hip_stream) {
+    if (int rc = l2norm_check(p)) return rc;
+    if (!k || !v || !k_out || !v_out) return fail(KVC_ERR_INVALID, "k, v, k_out and v_out must be non-NULL");
+    const int es = esize_of(p->dtype);
+    if (int rc = check_strides("k", es, p->k_stride_b, p->k_stride_h, p->k_stride_l, k)) return rc;
+    if (int rc = check_strides("v", es, p->v_stride_b, p->v_stride_h, p->v_stride_l, v)) return rc;
+    if (((uintptr_t)k_out) % 16 || ((uintptr_t)v_out) % 16) return fail(KVC_ERR_ALIGNMENT, "outputs not 16-byte aligned");
+    if (p->out_stride_h && (p->out_stride_h < (int64_t)p->k * p->head_dim || (p->out_stride_h * es) % 16))
+        return fail(KVC_ERR_INVALID, "out_stride_h smaller than k * head_dim, or not a multiple of 16 bytes");
+    const L2Layout l = l2norm_carve(p);
+    if (!workspace || ((uintptr_t)workspace) % 256 || workspace_bytes < l.total)
+        return fail(KVC_ERR_WORKSPACE, "kvc_l2norm_compress needs %zu bytes of 256-byte aligned workspace", l.total);
+    char* ws = static_cast<char*>(workspace);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const int heads = p->bsz * p->n_q_heads;
+    kvc::L2NormArgs na;
+    na.k = k; na.norms = norms_out ? norms_out : ws + l.norms;
+    na.stride_b = p->k_stride_b; na.stride_h = p->k_stride_h; na.stride_l = p->k_stride_l;
+    na.bsz = p->bsz; na.n_q_heads = p->n_q_heads; na.n_kv_heads = p->n_kv_heads; na.q_len = p->q_len; na.head_dim = p->head_dim;
+    if (int rc = kvc::launch_l2norm(na, p->dtype, st)) return fail(rc, "l2norm launch failed");
+    kvc::RaggedSortArgs sa;
+    sa.scores = na.norms; sa.caps = nullptr;
+    sa.idx_out = idx_out ? idx_out : reinterpret_cast<int64_t*>(ws + l.idx);
+    sa.n = p->q_len; sa.heads = heads; sa.out_stride = p->k; sa.want_fixed = p->k; sa.ascending = 1;
+    if (int rc = kvc::launch_sort_prefix(sa, p->dtype, ws + l.sort, st)) return fail(rc, "sort prefix launch failed");
+    kvc::GatherArgs g[2];
+    for (int which = 0; which < 2; ++which) {
+        std::memset(&g[which], 0, sizeof(g[which]));
+        g[which].src.p[0] = which ? v : k;
+        g[which].out.p[0] = which ? v_out : k_out;
+        g[which].idx.p[0] = sa.idx_out;
+        g[which].k.v[0] = p->k;
+        g[which].out_head_bytes.v[0] = p->out_stride_h * es;
+        g[which].n_items = 1; g[which].k_max = p->k;
+        g[which].stride_b = which ? p->v_stride_b : p->k_stride_b;
+        g[which].stride_h = which ? p->v_stride_h : p->k_stride_h;
+        g[which].stride_l = which ? p->v_stride_l : p->k_stride_l;
+        g[which].bsz = p->bsz; g[which].n_q_heads = p->n_q_heads; g[which].group = p->n_q_heads / p->n_kv_heads;
+        g[which].q_len = p->q_len; g[which].window = 0;
+        g[which].esize = es; g[which].row_bytes = p->head_dim * es;
+    }
+    return enqueue_gather(&g[0], &g[1], st);
+}
+
 __attribute__((visibility("default"))) int kvc_ragged_decode_step(const kvc_ragged_decode_params* p, const void* q, const void* k_new,
                                                                   const void* v_new, void* k_flat, void* v_flat, const int64_t* seg_off,
                                                                   const int32_t* seg_len, void* out, void* hip_stream) {

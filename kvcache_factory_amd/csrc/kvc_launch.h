@@ -80,6 +80,15 @@ struct RaggedSortArgs {    // sort_prefix_kernel (AdaKV / HeadKV)
     const int32_t* caps;   // [heads] device: how many leading indices of the descending sort each head keeps
     int64_t* idx_out;      // [heads][out_stride]
     int n, heads, out_stride;
+    int want_fixed = 0;    // caps == nullptr: leading indices kept by every head (0 = the whole sort)
+    int ascending = 0;     // 1: torch-CPU's ascending sort (L2Norm's argsort, pyramidkv_utils.py:420)
+};
+
+struct L2NormArgs {        // l2norm_kernel (L2NormCluster, pyramidkv_utils.py:419)
+    const void* k;         // [bsz][n_kv_heads][q_len][head_dim] by strides (elements)
+    void* norms;           // [bsz][n_q_heads][q_len] dtype: the norm of KV head h / group in every one of its query-head rows
+    int64_t stride_b, stride_h, stride_l;
+    int bsz, n_q_heads, n_kv_heads, q_len, head_dim;
 };
 
 struct RaggedArgs {        // ragged_head_stats_kernel / ragged_budget_kernel (AdaKV budgets)
@@ -145,6 +154,7 @@ size_t select_exact_scratch_bytes(int heads, int n, int k);     // per item
 int launch_gather(const GatherPair& p, hipStream_t st);
 int launch_decode_step(const DecodeArgs& a, int dtype, int head_dim, hipStream_t st);
 int launch_sort_prefix(const RaggedSortArgs& a, int dtype, void* scratch, hipStream_t st);
+int launch_l2norm(const L2NormArgs& a, int dtype, hipStream_t st);
 size_t sort_prefix_scratch_bytes(int heads, int n);
 int launch_ragged_plan(const RaggedArgs& a, int dtype, int bsz, hipStream_t st);
 int launch_ragged_head_stats(const RaggedArgs& a, int dtype, int bsz, hipStream_t st);

@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(64) void sort_prefix_kernel(const RaggedSortArgs a,
     int* stack = reinterpret_cast<int*>(smem);                        // 3 * 96 ints
     u64* lds_arr = reinterpret_cast<u64*>(smem + 1152);
     const int lane = threadIdx.x, head = blockIdx.x, n = a.n;
-    int want = a.caps ? a.caps[head] : n;
+    int want = a.caps ? a.caps[head] : (a.want_fixed > 0 ? a.want_fixed : n);
     want = want < 0 ? 0 : (want > n ? n : want);
     const raw* s = reinterpret_cast<const raw*>(a.scores) + (int64_t)head * n;
     int64_t* out = a.idx_out + (int64_t)head * a.out_stride;
@@ -1064,8 +1064,10 @@ __global__ __launch_bounds__(64) void sort_prefix_kernel(const RaggedSortArgs a,
     u64* const hs = gscratch + (int64_t)head * per_head;
     glb_int* const lists = (glb_int*)(hs + (arr_in_lds ? 0 : n));
     lds_u64* const larr = (lds_u64*)lds_arr;
+    // ascending order = the descending program on complemented keys (comp(a, b) = key'(a) > key'(b) <=> key(a) < key(b))
+    const uint32_t flip = a.ascending ? 0xffffffffu : 0u;
     if (arr_in_lds) {
-        for (int i = lane; i < n; i += 64) larr[i] = ((u64)Key<DT>::of(s[i]) << 32) | (uint32_t)i;
+        for (int i = lane; i < n; i += 64) larr[i] = ((u64)(Key<DT>::of(s[i]) ^ flip) << 32) | (uint32_t)i;
         __syncthreads();
         WaveSel<lds_u64> S{larr, lists, lists + (n / 2 + 2), (lds_int*)(larr + n), lane};
         S.small_bytes = list_bytes;
@@ -1076,7 +1078,7 @@ __global__ __launch_bounds__(64) void sort_prefix_kernel(const RaggedSortArgs a,
         S.sort_prefix_to(0, n, want, (lds_int*)stack, (glb_i64*)out);
     } else {
         glb_u64* const garr = (glb_u64*)hs;
-        for (int i = lane; i < n; i += 64) garr[i] = ((u64)Key<DT>::of(s[i]) << 32) | (uint32_t)i;
+        for (int i = lane; i < n; i += 64) garr[i] = ((u64)(Key<DT>::of(s[i]) ^ flip) << 32) | (uint32_t)i;
         __syncthreads();
         WaveSel<glb_u64> S{garr, lists, lists + (n / 2 + 2), (lds_int*)larr, lane};
         S.small_bytes = list_bytes;

@@ -2,15 +2,15 @@
 
 Call once BEFORE building the model, exactly like the reference (run_longbench.py:382-384); the per-layer knobs are
 then written onto `model.model.layers[i].self_attn.config.*` (run_longbench.py:253-261) and read by init_*.
-Methods in scope: "pyramidkv", "snapkv", "h2o", "streamingllm", and "adakv", "headkv"; "fullkv" leaves the
-model untouched (:86).  The reference's other method strings (cam, l2norm, think, minference) are out of scope and raise.
+Methods in scope: "pyramidkv", "snapkv", "h2o", "streamingllm", "adakv", "headkv" and (N4) "l2norm"; "fullkv"
+leaves the model untouched (:86).  The reference's other method strings (cam, think, minference) are out of scope and raise.
 The reference also rebinds `prepare_inputs_for_generation` to reset `kv_seq_len` (llama_model.py:2598-2612); with
 transformers 5.x that bookkeeping lives in the cache layer (cache.CompressedDynamicLayer), so nothing else is patched.
 """
 import transformers
 
-_IN_SCOPE = ("pyramidkv", "snapkv", "h2o", "streamingllm", "adakv", "headkv")
-_OUT_OF_SCOPE = ("cam", "l2norm", "think", "minference")
+_IN_SCOPE = ("pyramidkv", "snapkv", "h2o", "streamingllm", "adakv", "headkv", "l2norm")
+_OUT_OF_SCOPE = ("cam", "think", "minference")
 _ORIGINALS = {}
 
 

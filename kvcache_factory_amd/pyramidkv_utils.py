@@ -10,6 +10,7 @@ by one call into the HIP library (include/kvc.h: kvc_compress).  Differences, al
   * the reference prints its budget on every call (pyramidkv_utils.py:217,312,539,601); here that is
     opt-in: set `kvcache_factory_amd.pyramidkv_utils.VERBOSE = True` (or KVC_VERBOSE=1).
   * `merge` (LOOK-M pivot merge, :119-170) is out of scope: anything but None raises.
+  * L2NormCluster (:394-429) is built; CAM and ThinK are not.
   * tensors must live on the GPU: there is no CPU / eager fallback.
   * `PrefillBatch` (not in the reference): the patched forwards hand every layer's (K, window-Q, V) to it and every
     GROUP_LAYERS-th layer (and the last) flushes the parked ones through ONE kvc_compress_batch call on a side stream,
@@ -125,7 +126,7 @@ class PrefillBatch:
         alloc(bsz, n_heads, capacity_rows, head_dim, dtype, device) -> (k_buf, v_buf): optional owner-provided output
         buffers (a decode cache with spare rows); K' / V' are then written straight into them and sink gets views."""
         bsz, num_heads, q_len, head_dim = cluster._prefill_shapes(key_states, query_states)
-        if q_len < cluster.max_capacity_prompt or cluster._method == _kvc.H2O:
+        if q_len < cluster.max_capacity_prompt or cluster._method in (_kvc.H2O, _kvc.L2NORM):
             return False
         n_keep = cluster._budget(q_len)
         _say(f"{cluster._name} max_capacity_prompt {n_keep if cluster._method == _kvc.PYRAMIDKV else cluster.max_capacity_prompt}")
@@ -229,6 +230,34 @@ class H2OKVCluster(_KVCluster):
 class StreamingLLMKVCluster(_KVCluster):
     """pyramidkv_utils.py:578-620: no scoring, keeps the first cap-W and the last W tokens."""
     _name, _method = "StreamingLLM", _kvc.STREAMINGLLM
+
+
+class L2NormCluster:
+    """pyramidkv_utils.py:394-429: keep the max_capacity_prompt tokens of every head whose KEY has the smallest L2
+    norm, in ascending norm order — no query, no window, no pooling.  Same constructor, reset and update_kv signature as the
+    reference; the norms (torch-CPU's accumulation order), the ascending sort (torch-CPU's order of equal norms) and the
+    gather run in the HIP library (kvc_l2norm_compress)."""
+    _name, _method = "L2Norm", _kvc.L2NORM
+    merge = None
+
+    def __init__(self, max_capacity_prompt: int = 256 + 64, layer_idx: int = 0, skip_layers=()):
+        self.reset(max_capacity_prompt, layer_idx, skip_layers)
+
+    def reset(self, max_capacity_prompt: int = 256 + 64, layer_idx: int = 0, skip_layers=()):
+        self.max_capacity_prompt, self.layer_idx, self.skip_layers = max_capacity_prompt, layer_idx, list(skip_layers)
+
+    def _prefill_shapes(self, key_states, query_states):
+        assert key_states.shape[-2] == query_states.shape[-2]              # :407 "check if prefix phase"
+        return query_states.shape
+
+    def update_kv(self, key_states, query_states, value_states, attention_mask, num_key_value_groups):
+        bsz, num_heads, q_len, head_dim = self._prefill_shapes(key_states, query_states)
+        _say(f"L2Norm max_capacity_prompt {self.max_capacity_prompt}")
+        if q_len < self.max_capacity_prompt:                               # :413 pass-through, same objects
+            return key_states, value_states
+        if self.layer_idx in self.skip_layers:                             # :415
+            return key_states, value_states
+        return _kvc.l2norm_compress(key_states, value_states, self.max_capacity_prompt, n_q_heads=num_heads)
 
 
 class _RaggedCluster:
@@ -351,6 +380,16 @@ def init_H2O(self):
 def init_StreamingLLM(self):
     """pyramidkv_utils.py:1011-1031 (default cap 2048)."""
     _init(self, StreamingLLMKVCluster, 2048)
+
+
+def init_l2norm(self):
+    """pyramidkv_utils.py:954-968 (defaults: cap 4096, skip_layers [0, 1]); the cluster carries the MODULE's layer index."""
+    if not hasattr(self, "kv_cluster"):
+        for name, val in (("max_capacity_prompt", 4096), ("layer_idx", 0), ("skip_layers", [0, 1])):
+            if not hasattr(self.config, name):
+                setattr(self.config, name, val)
+    self.kv_cluster = L2NormCluster(max_capacity_prompt=self.config.max_capacity_prompt, layer_idx=self.layer_idx,
+                                    skip_layers=self.config.skip_layers)
 
 
 def init_adakv(self):

@@ -104,6 +104,44 @@ def run_ragged_case(c):
     return meta, out
 
 
+def run_l2norm_case(c):
+    """L2NormCluster.update_kv (pyramidkv_utils.py:394-429): stored are the kept indices per head (the leading
+    max_capacity_prompt entries of the reference's argsort), the token norms (small cases) and SHA-256 of K' / V'."""
+    dtype = DT[c["dtype"]]
+    q, k, v = synth.make_qkv(c["Hq"], c["Hkv"], c["L"], c["D"], dtype, c["seed"], peaky=c.get("peaky", False), expanded=True)
+    if c.get("coarse_k"):        # keys on a coarse grid: many equal norms
+        k = (k.float() * 2).round().div(2).to(dtype)
+    cl = ref.L2NormCluster(max_capacity_prompt=c["cap"], layer_idx=c.get("layer_idx", 5), skip_layers=c.get("skip_layers", [0, 1]))
+    taps = []
+    orig = torch.Tensor.argsort
+
+    def argsort(t, *a, **kwa):
+        r = orig(t, *a, **kwa)
+        taps.append((t.detach().clone(), r.detach().clone()))
+        return r
+    torch.Tensor.argsort = argsort
+    try:
+        t0 = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            ko, vo = cl.update_kv(k, q, v, None, c["Hq"] // c["Hkv"])
+        dt = time.time() - t0
+    finally:
+        torch.Tensor.argsort = orig
+    meta = dict(c)
+    meta["ref_seconds"] = round(dt, 4)
+    meta["passthrough"] = bool(ko is k and vo is v)
+    meta["out_shape"] = list(ko.shape)
+    meta["k_out_sha256"], meta["v_out_sha256"] = sha(ko), sha(vo)
+    out = {}
+    if taps:
+        norms, order = taps[0]
+        meta["norms_sha256"] = sha(norms[0])
+        out["indices"] = order[0, :, :c["cap"]].numpy().astype(np.int64)
+        if c["L"] <= 1100:
+            out["norms"] = raw_bits(norms[0])
+    return meta, out
+
+
 def make_cluster(c):
     kw = dict(window_size=c["W"], max_capacity_prompt=c["cap"], kernel_size=c["kernel"], pooling=c["pooling"])
     m = c["method"]
@@ -217,6 +255,17 @@ def cases():
     add("adakv_bf16_passthrough", method="adakv", dtype="bf16", Hq=4, Hkv=2, L=60, D=64, W=8, cap=128, kernel=7, pooling="maxpool", floor=0.2, normalize=True)
     add("adakv_8k_bf16", method="adakv", dtype="bf16", Hq=32, Hkv=8, L=8000, D=128, W=8, cap=128, kernel=7, pooling="maxpool", floor=0.2, normalize=True, seed=0)
     add("adakv_8k_bf16_peaky", method="adakv", dtype="bf16", Hq=32, Hkv=8, L=8000, D=128, W=8, cap=128, kernel=7, pooling="maxpool", floor=0.2, normalize=True, seed=1, peaky=True)
+    # ---- L2Norm (smallest key norms, ascending; no window, no query) ----
+    for dt in ("bf16", "fp16", "fp32"):
+        add(f"l2norm_{dt}_L600", method="l2norm", layer_idx=5, dtype=dt, Hq=8, Hkv=2, L=600, D=128, cap=96)
+        add(f"l2norm_{dt}_L257_D64", method="l2norm", layer_idx=5, dtype=dt, Hq=4, Hkv=4, L=257, D=64, cap=40)
+    add("l2norm_bf16_coarse_L1024", method="l2norm", layer_idx=5, dtype="bf16", Hq=8, Hkv=2, L=1024, D=128, cap=300, coarse_k=True)
+    add("l2norm_fp16_coarse_L1024", method="l2norm", layer_idx=5, dtype="fp16", Hq=8, Hkv=2, L=1024, D=128, cap=1024, coarse_k=True)   # cap == L: the whole sort
+    add("l2norm_bf16_passthrough", method="l2norm", layer_idx=5, dtype="bf16", Hq=4, Hkv=2, L=60, D=64, cap=128)
+    add("l2norm_bf16_skip_layer", method="l2norm", dtype="bf16", Hq=4, Hkv=2, L=300, D=64, cap=64, layer_idx=1)
+    add("l2norm_8k_bf16", method="l2norm", layer_idx=5, dtype="bf16", Hq=32, Hkv=8, L=8000, D=128, cap=128, seed=0)
+    add("l2norm_8k_bf16_cap4096", method="l2norm", layer_idx=5, dtype="bf16", Hq=32, Hkv=8, L=8000, D=128, cap=4096, seed=0)
+    add("l2norm_32k_bf16", method="l2norm", layer_idx=5, dtype="bf16", Hq=8, Hkv=2, L=32000, D=128, cap=4096, seed=0)
     return cs
 
 
@@ -235,6 +284,8 @@ def main():
         t0 = time.time()
         if c["method"] in ("adakv", "headkv"):
             meta, arrays = run_ragged_case(c)
+        elif c["method"] == "l2norm":
+            meta, arrays = run_l2norm_case(c)
         else:
             meta, arrays = run_case(c, store_scores=small)
         manifest[c["name"]] = meta

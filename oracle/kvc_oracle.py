@@ -59,6 +59,7 @@ def lib():
         L.kvco_sort_desc.argtypes = [pp, vp, i64p, vp]
         L.kvco_adakv_caps.argtypes = [pp, vp, ctypes.c_int64, ctypes.c_double, ctypes.c_int, vp]
         L.kvco_ragged_gather.argtypes = [pp, vp, ctypes.c_int64, ctypes.c_int64, i64p, vp, vp]
+        L.kvco_l2norm.argtypes = [pp, vp, vp, vp, i64p, vp, vp]
         L.kvco_pyramid_k.argtypes = [ctypes.c_int64] * 6
         L.kvco_pyramid_k.restype = ctypes.c_int64
         L.kvco_exp_u20.argtypes = [ctypes.c_float]
@@ -204,6 +205,26 @@ def ragged(q, k, v, window, max_capacity_prompt, kernel_size=7, pooling="maxpool
     _rc(lib().kvco_ragged_gather(ctypes.byref(p), _ptr(k), k.stride(1), k.stride(2), _ptr(idx), _ptr(caps), _ptr(kf)), "ragged_gather")
     _rc(lib().kvco_ragged_gather(ctypes.byref(p), _ptr(v), v.stride(1), v.stride(2), _ptr(idx), _ptr(caps), _ptr(vf)), "ragged_gather")
     return kf, vf, lens.to(torch.int32), caps, idx, sc
+
+
+def l2norm(k, v, max_capacity_prompt, n_q_heads, n_threads=0):
+    """L2NormCluster.update_kv (pyramidkv_utils.py:394-429) on k, v [1, Hq or Hkv, L, D]: the max_capacity_prompt smallest-norm
+    keys per head, ascending.  Returns (k_out [1, Hq, cap, D], v_out, idx int64 [Hq, cap], norms [Hq, L] dtype)."""
+    _check_inner(k), _check_inner(v)
+    p = Params()
+    p.dtype = _DTYPE[k.dtype]
+    p.n_q_heads, p.n_kv_heads = n_q_heads, k.shape[1]
+    p.q_len, p.head_dim = k.shape[2], k.shape[3]
+    p.window, p.k, p.n_threads = 0, max_capacity_prompt, n_threads
+    p.k_stride_h, p.k_stride_l = k.stride(1), k.stride(2)
+    p.v_stride_h, p.v_stride_l = v.stride(1), v.stride(2)
+    L, D, cap = k.shape[2], k.shape[3], max_capacity_prompt
+    norms = torch.empty(n_q_heads, L, dtype=k.dtype)
+    idx = torch.empty(n_q_heads, cap, dtype=torch.int64)
+    ko = torch.empty(1, n_q_heads, cap, D, dtype=k.dtype)
+    vo = torch.empty_like(ko)
+    _rc(lib().kvco_l2norm(ctypes.byref(p), _ptr(k), _ptr(v), _ptr(norms), _ptr(idx), _ptr(ko), _ptr(vo)), "l2norm")
+    return ko, vo, idx, norms
 
 
 def pyramid_k(cap, window, q_len, layer_idx, n_layers, beta=20):

@@ -46,3 +46,16 @@ def oracle_compress_batch(method, qs, ks, vs, window, keeps, kernel_size=5, pool
             r = (kb[:, :, :rows], vb[:, :, :rows], r[2])
         ko.append(r[0]); vo.append(r[1]); ix.append(r[2])
     return (ko, vo, ix) if return_indices else (ko, vo)
+
+
+def oracle_l2norm_compress(k, v, rows, n_q_heads=None, return_indices=False, return_norms=False, out=None):
+    """Stand-in for _kvc.l2norm_compress (host-logic tests only)."""
+    assert k.shape[0] == 1 and out is None
+    hq = n_q_heads if n_q_heads is not None else k.shape[1]
+    ko, vo, idx, norms = O.l2norm(k.contiguous(), v.contiguous(), rows, hq)
+    res = [ko, vo]
+    if return_indices:
+        res.append(idx[None])
+    if return_norms:
+        res.append(norms[None])
+    return tuple(res)

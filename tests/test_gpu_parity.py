@@ -1000,3 +1000,96 @@ def test_exact_ties_on_rising_scores(kvc, oracle, gpu_device, n, k, dtype):
     want, _ = oracle.topk(sc, k, oracle.TIES_TORCH)
     got = kvc.select(sc[None].to(gpu_device), k, "torch_cpu")[0].cpu()
     assert torch.equal(got, want)
+
+
+L2N = lambda m: m["method"] == "l2norm" and not m["passthrough"]          # noqa: E731
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", G.names(L2N))
+def test_l2norm_vs_oracle_and_reference(kvc, oracle, gpu_device, name):
+    """SURVEY 8f N4, L2NormCluster.update_kv (pyramidkv_utils.py:394-429) through kvc_l2norm_compress: norms bit for bit with
+    the oracle (torch-CPU's accumulation order), kept indices in torch-CPU's ascending-sort order — the std::sort emulation
+    on complemented keys, array in LDS (L <= 18000) or in the workspace (32k) — and K' / V' equal to what the imported
+    reference produced (SHA-256; 16-bit dtypes.  fp32: torch fuses its fp32 norm's multiply-add, ~1 % of norms differ in the
+    last place — heads whose norms agree must agree on every index).  K, V in the reference's expanded form and GQA-native."""
+    m = G.MANIFEST[name]
+    a = G.arrays(name)
+    q, k, v = G.inputs(m)
+    if m.get("coarse_k"):
+        k = (k.float() * 2).round().div(2).to(k.dtype)
+    g = m["Hq"] // m["Hkv"]
+    want = torch.from_numpy(a["indices"])
+    ko_o, vo_o, idx_o, norms_o = oracle.l2norm(k, v, m["cap"], m["Hq"])
+    for kk, vv in ((k, v), (k[:, ::g].contiguous(), v[:, ::g].contiguous())):
+        ko, vo, idx, norms = kvc.l2norm_compress(kk.to(gpu_device), vv.to(gpu_device), m["cap"], n_q_heads=m["Hq"],
+                                                 return_indices=True, return_norms=True)
+        assert torch.equal(G.bits(norms[0].cpu()), G.bits(norms_o))                 # tolerance: 0 ulp vs the oracle
+        assert torch.equal(idx[0].cpu(), idx_o)
+        assert torch.equal(G.bits(ko.cpu()), G.bits(ko_o)) and torch.equal(G.bits(vo.cpu()), G.bits(vo_o))
+        if m["dtype"] != "fp32":
+            assert torch.equal(idx[0].cpu(), want)
+            assert G.sha(ko.cpu()) == m["k_out_sha256"] and G.sha(vo.cpu()) == m["v_out_sha256"]
+        else:
+            same = (G.bits(norms[0].cpu()) == torch.from_numpy(a["norms"])).all(dim=1)
+            for h in range(m["Hq"]):
+                if bool(same[h]):
+                    assert torch.equal(idx[0, h].cpu(), want[h])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("L,rows,D", [(300, 1, 64), (300, 300, 64), (1000, 17, 128), (5000, 2500, 128), (20000, 313, 128), (18001, 18001, 64)])
+def test_l2norm_shapes_and_caller_buffers(kvc, oracle, gpu_device, L, rows, D, dtype):
+    """kvc_l2norm_compress over the corners of the sort (rows = 1, rows = L: the whole sort, array in LDS and in the workspace)
+    and with the outputs written into a caller's [1, H_q, capacity, D] buffers (out_stride_h): equal to the oracle."""
+    qq, k, v = G.synth.make_qkv(4, 2, L, D, dtype, 7000 + L + rows)
+    k = (k.float() * 4).round().div(4).to(dtype)                                     # coarse keys: many equal norms
+    ko_o, vo_o, idx_o, _ = oracle.l2norm(k, v, rows, 4)
+    kb = torch.zeros(1, 4, rows + 5, D, dtype=dtype, device=gpu_device)
+    vb = torch.zeros_like(kb)
+    ko, vo, idx = kvc.l2norm_compress(k.to(gpu_device), v.to(gpu_device), rows, n_q_heads=4, return_indices=True, out=(kb, vb))
+    assert torch.equal(idx[0].cpu(), idx_o)
+    assert ko.data_ptr() == kb.data_ptr() and torch.equal(G.bits(ko.cpu()), G.bits(ko_o)) and torch.equal(G.bits(vo.cpu()), G.bits(vo_o))
+    assert float(kb[:, :, rows:].abs().max()) == 0.0                                # spare rows untouched
+
+
+@pytest.mark.gpu
+def test_l2norm_patched_model_on_gpu(kvc, oracle, gpu_device):
+    """replace_llama("l2norm") on a small bf16 Llama ON THE GPU: skipped layers keep the whole prompt, the others keep
+    max_capacity_prompt rows equal to the oracle's L2Norm of the K/V the cluster saw; decode (fused kvc_decode_step over the
+    split cache) appends and generation runs."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from kvcache_factory_amd import monkeypatch as mp, pyramidkv_utils as pu
+    cfg = LlamaConfig(hidden_size=4096, intermediate_size=256, num_hidden_layers=4, num_attention_heads=32,
+                      num_key_value_heads=8, head_dim=128, vocab_size=256, max_position_embeddings=4096,
+                      attn_implementation="sdpa")
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(cfg).to(torch.bfloat16).to(gpu_device).eval()
+    L, cap = 500, 64
+    ids = torch.randint(0, 256, (1, L), generator=torch.Generator().manual_seed(5)).to(gpu_device)
+    seen, orig = [], pu.L2NormCluster.update_kv
+
+    def spy(self, k, q, v, am, g):
+        r = orig(self, k, q, v, am, g)
+        seen.append((self.layer_idx, k.clone(), v.clone(), r[0].clone(), r[1].clone()))
+        return r
+    try:
+        mp.replace_llama("l2norm")
+        for layer in model.model.layers:
+            for name, val in (("max_capacity_prompt", cap), ("skip_layers", [0, 1])):
+                setattr(layer.self_attn.config, name, val)
+        pu.L2NormCluster.update_kv = spy
+        with torch.no_grad():
+            out = model.generate(ids, max_new_tokens=4, do_sample=False, use_cache=True, return_dict_in_generate=True)
+    finally:
+        pu.L2NormCluster.update_kv = orig
+        mp.replace_llama("fullkv")
+    assert [s[0] for s in seen] == [0, 1, 2, 3]
+    cache = out.past_key_values
+    assert [cache.layers[i].keys.shape[2] for i in range(4)] == [L + 3, L + 3, cap + 3, cap + 3]
+    for li, k, v, kc, vc in seen[2:]:
+        ko_o, vo_o, _, _ = oracle.l2norm(k.cpu(), v.cpu(), cap, 32)
+        assert torch.equal(G.bits(kc.cpu()), G.bits(ko_o)) and torch.equal(G.bits(vc.cpu()), G.bits(vo_o))
+        assert torch.equal(G.bits(cache.layers[li].keys[:, :, :cap].cpu()), G.bits(ko_o))
+    assert out.sequences.shape[1] == L + 4

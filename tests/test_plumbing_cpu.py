@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import golden_util as G
-from cpu_compress import oracle_compress, oracle_compress_batch
+from cpu_compress import oracle_compress, oracle_compress_batch, oracle_l2norm_compress
 from kvcache_factory_amd import _kvc, monkeypatch as mp, pyramidkv_utils as pu
 
 
@@ -16,6 +16,7 @@ from kvcache_factory_amd import _kvc, monkeypatch as mp, pyramidkv_utils as pu
 def cpu_backend(monkeypatch, oracle):
     monkeypatch.setattr(_kvc, "compress", oracle_compress)
     monkeypatch.setattr(_kvc, "compress_batch", oracle_compress_batch)
+    monkeypatch.setattr(_kvc, "l2norm_compress", oracle_l2norm_compress)
     monkeypatch.setattr(pu, "BATCH_LAYERS", False)       # these tests watch one update_kv per layer
     yield
 
@@ -105,7 +106,7 @@ def test_replace_llama_and_mistral_rebind_and_restore():
     MA = transformers.models.mistral.modeling_mistral.MistralAttention
     orig_l, orig_m = LA.forward, MA.forward
     try:
-        for method in ("pyramidkv", "snapkv", "h2o", "streamingllm", "adakv", "headkv"):
+        for method in ("pyramidkv", "snapkv", "h2o", "streamingllm", "l2norm", "adakv", "headkv"):
             mp.replace_llama(method); mp.replace_mistral(method)
             assert LA.forward.kvc_method == method and MA.forward.kvc_method == method
         mp.replace_llama("no-such-method")               # unknown strings patch nothing (monkeypatch.py:19-87)
@@ -398,5 +399,55 @@ def test_decode_mask_is_trimmed_per_layer(cpu_backend):
             cache.layers[1]._stored -= 1; cache.layers[1].true_length -= 1
             with pytest.raises(RuntimeError, match="attention mask covers"):
                 attn(hs[:, :1], position_embeddings=pos1, attention_mask=torch.zeros(1, 1, 1, 20), past_key_values=cache)
+    finally:
+        mp.replace_llama("fullkv")
+
+
+def test_l2norm_cluster_and_factory(cpu_backend):
+    """L2NormCluster (pyramidkv_utils.py:394-429): constructor / reset signature, the two pass-through branches returning the
+    same objects (:413-416), the kept branch against the reference fixture, and init_l2norm's defaults (:954-968)."""
+    m = G.MANIFEST["l2norm_bf16_L600"]
+    q, k, v = G.inputs(m)
+    g = m["Hq"] // m["Hkv"]
+    for kk, vv in ((k, v), (k[:, ::g].contiguous(), v[:, ::g].contiguous())):      # expanded like the reference's caller, and GQA-native
+        ko, vo = pu.L2NormCluster(max_capacity_prompt=m["cap"], layer_idx=5, skip_layers=[0, 1]).update_kv(kk, q, vv, None, g)
+        assert list(ko.shape) == m["out_shape"]
+        assert G.sha(ko) == m["k_out_sha256"] and G.sha(vo) == m["v_out_sha256"]
+    ko, vo = pu.L2NormCluster(max_capacity_prompt=m["cap"], layer_idx=1, skip_layers=[0, 1]).update_kv(k, q, v, None, g)
+    assert ko is k and vo is v                                                       # skipped layer
+    ko, vo = pu.L2NormCluster(max_capacity_prompt=4096, layer_idx=5).update_kv(k, q, v, None, g)
+    assert ko is k and vo is v                                                       # prompt shorter than the budget
+    with pytest.raises(AssertionError):
+        pu.L2NormCluster(64).update_kv(k[:, :, :50], q, v, None, g)                  # :407
+
+    class Cfg:
+        pass
+
+    class Attn:
+        def __init__(self):
+            self.config, self.layer_idx = Cfg(), 7
+    a = Attn()
+    pu.init_l2norm(a)
+    assert (a.config.max_capacity_prompt, a.config.skip_layers) == (4096, [0, 1])
+    assert isinstance(a.kv_cluster, pu.L2NormCluster) and a.kv_cluster.layer_idx == 7
+    first = a.kv_cluster
+    a.config.max_capacity_prompt = 96
+    pu.init_l2norm(a)
+    assert a.kv_cluster is not first and a.kv_cluster.max_capacity_prompt == 96
+
+
+def test_l2norm_through_the_model(cpu_backend):
+    """replace_llama("l2norm") on a 3-layer Llama (CPU, oracle-backed compute): layers 0 and 1 are skipped and keep the whole
+    prompt, layer 2 keeps max_capacity_prompt rows; decode appends to each and generation runs."""
+    model = _llama(layers=3)
+    ids = torch.randint(0, 512, (1, 96))
+    mp.replace_llama("l2norm")
+    try:
+        model2 = _llama(layers=3)
+        _set_knobs(model2, max_capacity_prompt=40, skip_layers=[0, 1])
+        out = _generate(model2, ids, 3)
+        cache = out.past_key_values
+        assert [cache.layers[i].keys.shape[2] for i in range(3)] == [96 + 2, 96 + 2, 40 + 2]
+        assert cache.get_seq_length() == 96 + 2
     finally:
         mp.replace_llama("fullkv")
