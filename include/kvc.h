@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define KVC_VERSION 3
+#define KVC_VERSION 4
 
 typedef enum kvc_status {
     KVC_OK = 0,
@@ -251,6 +251,20 @@ int kvc_ragged_decode_step(const kvc_ragged_decode_params* p, const void* q, con
 size_t kvc_l2norm_workspace_bytes(const kvc_params* p);
 int kvc_l2norm_compress(const kvc_params* p, const void* k, const void* v, void* k_out, void* v_out, int64_t* idx_out,
                         void* norms_out, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* ---- merge_kv(key_states, value_states, indices, window_size, "pivot") (pyramidkv_utils.py:119-170) ------
+ * What SnapKV / PyramidKV / H2O update_kv return instead of the plain gather when their cluster was built with merge="pivot"
+ * (:337-339): every token selected by NO head ("dropped", the window included) is averaged into the kept key it is most
+ * similar to (cosine, first maximum) and its value into the value row of the same number; kept rows become the mean of
+ * themselves and what was merged into them.  idx: [b*n_q_heads][p->k] int64 on the device — the indices of the method's
+ * top-k (kvc_select / kvc_compress idx_out).  Outputs [b][n_q_heads][k + window][D]: k_out in the reference's key order
+ * [window rows, selected rows], v_out in its value order [selected rows, window rows] (the reference's two cats differ, :145 / :147,
+ * and the pivot found on the key order is applied to both).  head_dim must be 128 (hard-coded in the reference, :149);
+ * 16-bit dtypes.  pivot_out ([b*n_q_heads][q_len] int32: row [0, drop_len) = pivot of every dropped token, ascending position)
+ * and drop_len_out ([b] int32) may be NULL.  Arithmetic: see csrc/kvc_merge.hip.  Workspace: kvc_merge_workspace_bytes(p). */
+size_t kvc_merge_workspace_bytes(const kvc_params* p);
+int kvc_merge_pivot(const kvc_params* p, const void* k, const void* v, const int64_t* idx, void* k_out, void* v_out,
+                    int32_t* pivot_out, int32_t* drop_len_out, void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* Debug/parity aid: byte offsets inside the workspace of the intermediates kvc_scores leaves behind.
  * offs[0]=logits [b][h][L][W] dtype, offs[1]=row max [b][h][W] f32, offs[2]=row sum [b][h][W] f32.

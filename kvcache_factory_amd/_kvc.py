@@ -24,7 +24,8 @@ DOT_MODE = os.environ.get("KVC_DOT_MODE", "exact")      # default of every helpe
 EXPORTS = ("kvc_version", "kvc_last_error", "kvc_workspace_bytes", "kvc_compress", "kvc_scores", "kvc_select",
            "kvc_gather", "kvc_pyramid_k", "kvc_workspace_layout", "kvc_workspace_bytes_batch", "kvc_compress_batch",
            "kvc_select_workspace_bytes", "kvc_decode_step", "kvc_ragged_workspace_bytes", "kvc_ragged_plan",
-           "kvc_ragged_compact", "kvc_ragged_decode_step", "kvc_l2norm_workspace_bytes", "kvc_l2norm_compress")
+           "kvc_ragged_compact", "kvc_ragged_decode_step", "kvc_l2norm_workspace_bytes", "kvc_l2norm_compress",
+           "kvc_merge_workspace_bytes", "kvc_merge_pivot")
 
 
 class KvcError(RuntimeError):
@@ -95,6 +96,9 @@ def lib():
         L.kvc_l2norm_workspace_bytes.argtypes = [pp]
         L.kvc_l2norm_workspace_bytes.restype = sz
         L.kvc_l2norm_compress.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+        L.kvc_merge_workspace_bytes.argtypes = [pp]
+        L.kvc_merge_workspace_bytes.restype = sz
+        L.kvc_merge_pivot.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         _lib = L
     return _lib
 
@@ -387,6 +391,46 @@ def ragged_decode_step(q, k_new, v_new, k_flat, v_flat, seg_off, seg_len, append
     _check(_call(dev, lib().kvc_ragged_decode_step, ctypes.byref(p), _ptr(q), _ptr(k_new), _ptr(v_new), _ptr(k_flat), _ptr(v_flat),
                  _ptr(seg_off), _ptr(seg_len), _ptr(out), _stream(dev)))
     return out
+
+
+def compress_merge(method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu", n_q_heads=None):
+    """update_kv with merge="pivot": the method's scores and top-k (StreamingLLM: the first n_keep positions, :610-611), then
+    merge_kv instead of the gather (pyramidkv_utils.py:337-339).  Returns (key_states', value_states')."""
+    if method == STREAMINGLLM:
+        hq = n_q_heads if n_q_heads is not None else k.shape[1]
+        idx = torch.arange(n_keep, device=k.device, dtype=torch.int64).expand(k.shape[0], hq, n_keep).contiguous()
+    else:
+        sc = scores(method, q, k, window, kernel_size, pooling)
+        idx = select(sc, n_keep, tie_mode)
+    return merge_pivot(method, k, v, idx, window)
+
+
+def merge_pivot(method, k, v, idx, window, return_pivot=False, out=None):
+    """merge_kv(key_states, value_states, indices, window_size, "pivot") (pyramidkv_utils.py:119-170) on the GPU (kvc_merge_pivot)
+    for idx [b, H_q, n_keep] int64, the indices the method's top-k selected.  Returns (k_out [b, H_q, n_keep + W, D] in the
+    reference's key order [window, selected], v_out in its value order [selected, window][, pivot int32 [b, H_q, drop_len]])."""
+    _require_gpu(k, v, idx)
+    k, v = _last_dim_contig(k), _last_dim_contig(v)
+    dev = _one_device(k, v, idx, *(out if out is not None else ()))
+    bsz, hq, n_keep = idx.shape
+    idx = idx.contiguous()
+    p = make_params(method, None, k, v, window, n_keep, 1, None)
+    p.n_q_heads = hq
+    L, D = k.shape[2], k.shape[3]
+    k_out, v_out, p.out_stride_h = _out_views(out, bsz, hq, n_keep + window, D, k.dtype, dev)
+    nbytes = lib().kvc_merge_workspace_bytes(ctypes.byref(p))
+    if nbytes == 0:
+        raise KvcError(ERR_INVALID, lib().kvc_last_error().decode())
+    ws = workspace(dev, nbytes)
+    pivot = torch.empty(bsz * hq, L, dtype=torch.int32, device=dev) if return_pivot else None
+    dl = torch.empty(bsz, dtype=torch.int32, device=dev) if return_pivot else None
+    _check(_call(dev, lib().kvc_merge_pivot, ctypes.byref(p), _ptr(k), _ptr(v), _ptr(idx), _ptr(k_out), _ptr(v_out), _ptr(pivot), _ptr(dl),
+                 _ptr(ws), nbytes, _stream(dev)))
+    res = [k_out[:, :, :n_keep + window], v_out[:, :, :n_keep + window]]
+    if return_pivot:
+        m = int(dl.max())
+        res.append(pivot.view(bsz, hq, L)[:, :, :m])
+    return tuple(res)
 
 
 def l2norm_compress(k, v, rows, n_q_heads=None, return_indices=False, return_norms=False, out=None):

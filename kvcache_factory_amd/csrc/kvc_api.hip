@@ -712,6 +712,71 @@ __attribute__((visibility("default"))) int kvc_l2norm_compress(const kvc_params*
     return enqueue_gather(&g[0], &g[1], st);
 }
 
+// ---- merge_kv(..., "pivot") (pyramidkv_utils.py:119-170) ----------------------------------------------------
+namespace {
+struct MergeLayout { size_t mask, drop, drop_len, kn, pivot, total; };
+MergeLayout merge_carve(const kvc_params* p) {
+    MergeLayout l;
+    const size_t heads = (size_t)p->bsz * p->n_q_heads, L = (size_t)p->q_len, R = (size_t)p->k + p->window;
+    size_t off = 0;
+    l.mask = off;     off = align_up(off + (size_t)p->bsz * L * 4, 256);
+    l.drop = off;     off = align_up(off + (size_t)p->bsz * L * 4, 256);
+    l.drop_len = off; off = align_up(off + (size_t)p->bsz * 4, 256);
+    l.kn = off;       off = align_up(off + heads * R * 128 * 4, 256);
+    l.pivot = off;    off = align_up(off + heads * L * 4, 256);
+    l.total = off;
+    return l;
+}
+int merge_check(const kvc_params* p) {
+    if (int rc = validate(p, false)) return rc;
+    if (p->method != KVC_SNAPKV && p->method != KVC_PYRAMIDKV && p->method != KVC_H2O && p->method != KVC_STREAMINGLLM)
+        return fail(KVC_ERR_INVALID, "kvc_merge_pivot: merge_kv is reached from SnapKV / PyramidKV / H2O / StreamingLLM update_kv only");
+    if (p->head_dim != 128) return fail(KVC_ERR_UNSUPPORTED, "merge_kv hard-codes head_dim 128 (pyramidkv_utils.py:149), got %d", p->head_dim);
+    if (p->dtype == KVC_FP32) return fail(KVC_ERR_UNSUPPORTED, "merge_kv: fp32 not built (torch's fp32 GEMM order is not restated)");
+    if (p->k < 1) return fail(KVC_ERR_INVALID, "merge_kv needs k >= 1");
+    return KVC_OK;
+}
+}  // namespace
+
+__attribute__((visibility("default"))) size_t kvc_merge_workspace_bytes(const kvc_params* p) {
+    if (merge_check(p) != KVC_OK) return 0;
+    g_err[0] = 0;
+    return merge_carve(p).total;
+}
+
+__attribute__((visibility("default"))) int kvc_merge_pivot(const kvc_params* p, const void* k, const void* v, const int64_t* idx,
+                                                           void* k_out, void* v_out, int32_t* pivot_out, int32_t* drop_len_out,
+                                                           void* workspace, size_t workspace_bytes, void* hip_stream) {
+    if (int rc = merge_check(p)) return rc;
+    if (!k || !v || !idx || !k_out || !v_out) return fail(KVC_ERR_INVALID, "k, v, idx, k_out and v_out must be non-NULL");
+    const int es = esize_of(p->dtype);
+    if (int rc = check_strides("k", es, p->k_stride_b, p->k_stride_h, p->k_stride_l, k)) return rc;
+    if (int rc = check_strides("v", es, p->v_stride_b, p->v_stride_h, p->v_stride_l, v)) return rc;
+    if (((uintptr_t)k_out) % 16 || ((uintptr_t)v_out) % 16) return fail(KVC_ERR_ALIGNMENT, "outputs not 16-byte aligned");
+    const int64_t rows = (int64_t)p->k + p->window;
+    if (p->out_stride_h && (p->out_stride_h < rows * p->head_dim || (p->out_stride_h * es) % 16))
+        return fail(KVC_ERR_INVALID, "out_stride_h smaller than (k + window) * head_dim, or not a multiple of 16 bytes");
+    const MergeLayout l = merge_carve(p);
+    if (!workspace || ((uintptr_t)workspace) % 256 || workspace_bytes < l.total)
+        return fail(KVC_ERR_WORKSPACE, "kvc_merge_pivot needs %zu bytes of 256-byte aligned workspace", l.total);
+    char* ws = static_cast<char*>(workspace);
+    kvc::MergeArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.k = k; a.v = v; a.idx = idx; a.k_out = k_out; a.v_out = v_out;
+    a.mask = reinterpret_cast<int32_t*>(ws + l.mask);
+    a.drop = reinterpret_cast<int32_t*>(ws + l.drop);
+    a.drop_len = drop_len_out ? drop_len_out : reinterpret_cast<int32_t*>(ws + l.drop_len);
+    a.kn = reinterpret_cast<float*>(ws + l.kn);
+    a.pivot = pivot_out ? pivot_out : reinterpret_cast<int32_t*>(ws + l.pivot);
+    a.k_stride_b = p->k_stride_b; a.k_stride_h = p->k_stride_h; a.k_stride_l = p->k_stride_l;
+    a.v_stride_b = p->v_stride_b; a.v_stride_h = p->v_stride_h; a.v_stride_l = p->v_stride_l;
+    a.out_stride_h = p->out_stride_h;
+    a.bsz = p->bsz; a.n_q_heads = p->n_q_heads; a.group = p->n_q_heads / p->n_kv_heads; a.q_len = p->q_len;
+    a.window = p->window; a.n_keep = p->k; a.rows = (int)rows;
+    if (int rc = kvc::launch_merge(a, p->dtype, static_cast<hipStream_t>(hip_stream))) return fail(rc, "merge launch failed");
+    return hip_ok("merge launch");
+}
+
 __attribute__((visibility("default"))) int kvc_ragged_decode_step(const kvc_ragged_decode_params* p, const void* q, const void* k_new,
                                                                   const void* v_new, void* k_flat, void* v_flat, const int64_t* seg_off,
                                                                   const int32_t* seg_len, void* out, void* hip_stream) {

@@ -84,6 +84,19 @@ struct RaggedSortArgs {    // sort_prefix_kernel (AdaKV / HeadKV)
     int ascending = 0;     // 1: torch-CPU's ascending sort (L2Norm's argsort, pyramidkv_utils.py:420)
 };
 
+struct MergeArgs {         // merge_kv pivot merge (kvc_merge.hip)
+    const void* k; const void* v;
+    const int64_t* idx;    // [bsz * n_q_heads][n_keep]: the select stage's indices
+    void* k_out; void* v_out;
+    int32_t* mask;         // [bsz][q_len] workspace
+    int32_t* drop;         // [bsz][q_len]
+    int32_t* drop_len;     // [bsz]
+    float* kn;             // [bsz * n_q_heads][rows][128] normalised kept keys
+    int32_t* pivot;        // [bsz * n_q_heads][q_len]
+    int64_t k_stride_b, k_stride_h, k_stride_l, v_stride_b, v_stride_h, v_stride_l, out_stride_h;
+    int bsz, n_q_heads, group, q_len, window, n_keep, rows;      // rows = n_keep + window
+};
+
 struct L2NormArgs {        // l2norm_kernel (L2NormCluster, pyramidkv_utils.py:419)
     const void* k;         // [bsz][n_kv_heads][q_len][head_dim] by strides (elements)
     void* norms;           // [bsz][n_q_heads][q_len] dtype: the norm of KV head h / group in every one of its query-head rows
@@ -155,6 +168,7 @@ int launch_gather(const GatherPair& p, hipStream_t st);
 int launch_decode_step(const DecodeArgs& a, int dtype, int head_dim, hipStream_t st);
 int launch_sort_prefix(const RaggedSortArgs& a, int dtype, void* scratch, hipStream_t st);
 int launch_l2norm(const L2NormArgs& a, int dtype, hipStream_t st);
+int launch_merge(const MergeArgs& a, int dtype, hipStream_t st);
 size_t sort_prefix_scratch_bytes(int heads, int n);
 int launch_ragged_plan(const RaggedArgs& a, int dtype, int bsz, hipStream_t st);
 int launch_ragged_head_stats(const RaggedArgs& a, int dtype, int bsz, hipStream_t st);

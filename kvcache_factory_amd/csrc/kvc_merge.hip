@@ -1,0 +1,241 @@
+// kvc_merge.hip — SURVEY §8(f) N4: merge_kv(..., merge="pivot") (pyramidkv_utils.py:119-170, LOOK-M), the step SnapKV /
+// PyramidKV / H2O take instead of the plain gather when the cluster was built with merge="pivot" (:337-339).
+//
+// Reference, per head (all H_q heads; K, V repeat_kv-expanded):
+//   dropped  = the positions NO head selected — torch.isin against every head's indices (:131-134) — the window included;
+//   kept K   = [window rows, selected rows] (:145);   kept V = [selected rows, window rows] (:147)   (the orders differ);
+//   similarity = normalise(dropped K) @ normalise(kept K)^T, cosine, in the dtype (:149);  pivot = its first maximal column;
+//   merged   = (dropped + kept[pivot]) / 2 (:155, :158);  kept = scatter_reduce(kept, pivot, merged, 'mean', include_self) (:156, :160)
+//   — the pivot found on the KEY order is applied to the value rows of the same number.
+//
+// Here, six launches after the method's scoring + selection (the indices are the select stage's output):
+//   merge_mask_kernel     every selected index marks its position                                  (H_q * k threads)
+//   merge_drop_kernel     ordered compaction of the unmarked positions -> drop[], drop_len          (one workgroup per batch row)
+//   merge_kept_kernel     the normalised kept keys of every head, fp32 in the workspace             (one wave per row)
+//   merge_pivot_kernel    one thread per (head, dropped token): its normalised key in registers, the kept keys 64 rows at a
+//                         time through LDS (broadcast reads), a d-ascending fp32 FMA chain per pair (products of two 16-bit
+//                         values are exact in fp32, so the fused chain IS the sum of products), rounded to the dtype, first maximum
+//   merge_reduce_kernel   one wave per (head, kept row, K|V): walks the pivots 64 at a time (ballot -> ascending order), adds the
+//                         merged rows in fp32, then sum -> dtype, count -> dtype, quotient -> dtype
+// Arithmetic = oracle/kvc_oracle.cpp kvco_merge_pivot (norms in torch's 8-accumulator order, fp32 divides, one rounding each),
+// which equals the imported reference bit for bit on every fixture (tests/golden/merge_*).
+// Cost: the pivot stage is H_q * drop_len * (k + W) * D multiply-adds (4.2 G at 8k -> 128) on the fp32 VALU; everything else is
+// small.  The K scan of the scoring stage is unchanged.
+#include "kvc_common.h"
+#include "kvc_launch.h"
+
+namespace kvc {
+
+__global__ __launch_bounds__(256) void merge_mask_kernel(const MergeArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t per_b = (int64_t)a.n_q_heads * a.n_keep;
+    if (i >= per_b * a.bsz) return;
+    const int b = (int)(i / per_b);
+    a.mask[(int64_t)b * a.q_len + a.idx[i]] = 1;
+}
+
+// grid = bsz, block = 1024: drop[b][0 .. drop_len[b]) = ascending positions with mask == 0
+__global__ __launch_bounds__(1024) void merge_drop_kernel(const MergeArgs a) {
+    __shared__ int wave_cnt[16];
+    __shared__ int base_s;
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int32_t* mask = a.mask + (int64_t)b * a.q_len;
+    int32_t* drop = a.drop + (int64_t)b * a.q_len;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < a.q_len; j0 += 1024) {
+        const int j = j0 + tid;
+        const bool keep = j < a.q_len && mask[j] == 0;
+        const unsigned long long m = __ballot(keep);
+        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+        if (lane == 0) wave_cnt[wave] = __builtin_popcountll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (keep) drop[off + rank] = j;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wave_cnt[w]; base_s += t; }
+        __syncthreads();
+    }
+    if (tid == 0) a.drop_len[b] = base_s;
+}
+
+// torch-CPU's norm of one row held two elements per lane (head_dim 128): accumulator j sums the elements d with d % 8 == j in
+// ascending d, then the accumulators are added 0..7.  Lane l holds d = 2l, 2l + 1: accumulator (2l) % 8 and (2l + 1) % 8 get
+// their terms from lanes l, l + 4, l + 8, ... in that order.
+template <int DT>
+__device__ __forceinline__ float row_norm128(float x0, float x1, int lane) {
+    const float s0 = x0 * x0, s1 = x1 * x1;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+#pragma unroll
+    for (int step = 0; step < 16; ++step) {                                  // elements 8 * step .. 8 * step + 7 = lanes 4 * step .. + 3
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int src = 4 * step + q;
+            acc[2 * q] = acc[2 * q] + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s0), src));
+            acc[2 * q + 1] = acc[2 * q + 1] + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s1), src));
+        }
+    }
+    float tot = acc[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) tot = tot + acc[j];
+    return rnd<DT>(__builtin_sqrtf(tot));
+}
+
+// Source position of kept row r of head hb: KEY order [window, selected] / VALUE order [selected, window].
+__device__ __forceinline__ int64_t kept_pos(const MergeArgs& a, int64_t hb, int r, bool value_order) {
+    if (value_order) return r < a.n_keep ? a.idx[hb * a.n_keep + r] : (int64_t)(a.q_len - a.window) + (r - a.n_keep);
+    return r < a.window ? (int64_t)(a.q_len - a.window) + r : a.idx[hb * a.n_keep + (r - a.window)];
+}
+
+// grid = (R, bsz * H_q), block = 64: kn[hb][r][:] = dtype(x / norm) as fp32
+template <int DT>
+__global__ __launch_bounds__(64) void merge_kept_kernel(const MergeArgs a) {
+    typedef typename Dt<DT>::raw raw;
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const int64_t hb = blockIdx.y;
+    const int b = (int)(hb / a.n_q_heads), h = (int)(hb % a.n_q_heads);
+    const raw* row = reinterpret_cast<const raw*>(a.k) + (int64_t)b * a.k_stride_b + (int64_t)(h / a.group) * a.k_stride_h +
+                     kept_pos(a, hb, r, false) * a.k_stride_l;
+    const uint32_t w = reinterpret_cast<const uint32_t*>(row)[lane];
+    const float x0 = Dt<DT>::ld((raw)(w & 0xffffu)), x1 = Dt<DT>::ld((raw)(w >> 16));
+    const float n = row_norm128<DT>(x0, x1, lane);
+    float2 o;
+    o.x = rnd<DT>(x0 / n);
+    o.y = rnd<DT>(x1 / n);
+    reinterpret_cast<float2*>(a.kn + (hb * a.rows + r) * 128)[lane] = o;
+}
+
+// grid = (ceil(q_len / 256), bsz * H_q), block = 256: pivot[hb][p] for p < drop_len[b]
+template <int DT>
+__global__ __launch_bounds__(256) void merge_pivot_kernel(const MergeArgs a) {
+    __shared__ __attribute__((aligned(16))) float tile[64 * 128];                           // 64 kept rows at a time (32 KB)
+    typedef typename Dt<DT>::raw raw;
+    const int tid = threadIdx.x;
+    const int64_t hb = blockIdx.y;
+    const int b = (int)(hb / a.n_q_heads), h = (int)(hb % a.n_q_heads);
+    const int M = a.drop_len[b];
+    const int p0 = blockIdx.x * 256;
+    if (p0 >= M) return;                                                                    // uniform per workgroup
+    const int p = p0 + tid;
+    const bool live = p < M;
+    float x[128];
+    {
+        const int64_t pos = live ? a.drop[(int64_t)b * a.q_len + p] : 0;
+        const raw* row = reinterpret_cast<const raw*>(a.k) + (int64_t)b * a.k_stride_b + (int64_t)(h / a.group) * a.k_stride_h + pos * a.k_stride_l;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const uint4 v = reinterpret_cast<const uint4*>(row)[c];
+            const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float e0 = Dt<DT>::ld((raw)(wv[j] & 0xffffu)), e1 = Dt<DT>::ld((raw)(wv[j] >> 16));
+                x[8 * c + 2 * j] = e0;
+                x[8 * c + 2 * j + 1] = e1;
+                acc[2 * j] = acc[2 * j] + e0 * e0;
+                acc[2 * j + 1] = acc[2 * j + 1] + e1 * e1;
+            }
+        }
+        float tot = acc[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) tot = tot + acc[j];
+        const float n = rnd<DT>(__builtin_sqrtf(tot));
+#pragma unroll
+        for (int d = 0; d < 128; ++d) x[d] = rnd<DT>(x[d] / n);
+    }
+    int best = 0;
+    float bestv = 0.0f;
+    // (Measured alternatives: the kept rows through the scalar cache as SGPR operands — 482 us, the scalar cache cannot feed
+    // 4 096 waves; two rows per packed-fp32 FMA with the dropped row duplicated in register pairs — spills to AGPRs.)
+    const float* kn = a.kn + hb * a.rows * 128;
+    for (int r0 = 0; r0 < a.rows; r0 += 64) {
+        const int nr = a.rows - r0 < 64 ? a.rows - r0 : 64;
+        __syncthreads();
+        for (int i = tid; i < nr * 32; i += 256)
+            reinterpret_cast<float4*>(tile)[i] = reinterpret_cast<const float4*>(kn + (int64_t)r0 * 128)[i];
+        __syncthreads();
+        for (int r = 0; r < nr; ++r) {
+            const float4* t4 = reinterpret_cast<const float4*>(tile + r * 128);
+            float s = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                const float4 t = t4[c];
+                s = __builtin_fmaf(x[4 * c], t.x, s);
+                s = __builtin_fmaf(x[4 * c + 1], t.y, s);
+                s = __builtin_fmaf(x[4 * c + 2], t.z, s);
+                s = __builtin_fmaf(x[4 * c + 3], t.w, s);
+            }
+            s = rnd<DT>(s);
+            if ((r0 + r == 0) || s > bestv) { best = r0 + r; bestv = s; }
+        }
+    }
+    if (live) a.pivot[hb * a.q_len + p] = best;
+}
+
+// grid = (R, bsz * H_q, 2 {K, V}), block = 64: one kept row; lane l holds elements 2l, 2l + 1
+template <int DT>
+__global__ __launch_bounds__(64) void merge_reduce_kernel(const MergeArgs a) {
+    typedef typename Dt<DT>::raw raw;
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const bool is_v = blockIdx.z != 0;
+    const int64_t hb = blockIdx.y;
+    const int b = (int)(hb / a.n_q_heads), h = (int)(hb % a.n_q_heads);
+    const int64_t sb = is_v ? a.v_stride_b : a.k_stride_b, sh = is_v ? a.v_stride_h : a.k_stride_h, sl = is_v ? a.v_stride_l : a.k_stride_l;
+    const raw* base = reinterpret_cast<const raw*>(is_v ? a.v : a.k) + (int64_t)b * sb + (int64_t)(h / a.group) * sh;
+    const uint32_t ws = reinterpret_cast<const uint32_t*>(base + kept_pos(a, hb, r, is_v) * sl)[lane];
+    const float self0 = Dt<DT>::ld((raw)(ws & 0xffffu)), self1 = Dt<DT>::ld((raw)(ws >> 16));
+    float sum0 = self0, sum1 = self1;
+    int cnt = 1;
+    const int M = a.drop_len[b];
+    const int32_t* pv = a.pivot + hb * a.q_len;
+    const int32_t* drop = a.drop + (int64_t)b * a.q_len;
+    for (int p0 = 0; p0 < M; p0 += 64) {
+        const int p = p0 + lane;
+        const bool hit = p < M && pv[p] == r;
+        const int pos = hit ? drop[p] : 0;
+        unsigned long long m = __ballot(hit);
+        while (m) {
+            const int i = __builtin_ctzll(m);
+            m &= m - 1;
+            const int64_t src = __builtin_amdgcn_readlane(pos, i);
+            const uint32_t w = reinterpret_cast<const uint32_t*>(base + src * sl)[lane];
+            const float d0 = Dt<DT>::ld((raw)(w & 0xffffu)), d1 = Dt<DT>::ld((raw)(w >> 16));
+            sum0 = sum0 + rnd<DT>(rnd<DT>(d0 + self0) / 2.0f);
+            sum1 = sum1 + rnd<DT>(rnd<DT>(d1 + self1) / 2.0f);
+            ++cnt;
+        }
+    }
+    const float c = rnd<DT>((float)cnt);
+    const raw o0 = Dt<DT>::st(rnd<DT>(sum0) / c), o1 = Dt<DT>::st(rnd<DT>(sum1) / c);
+    const int64_t head_elems = a.out_stride_h ? a.out_stride_h : (int64_t)a.rows * 128;
+    raw* out = reinterpret_cast<raw*>(is_v ? a.v_out : a.k_out) + hb * head_elems + (int64_t)r * 128;
+    reinterpret_cast<uint32_t*>(out)[lane] = (uint32_t)o0 | ((uint32_t)o1 << 16);
+}
+
+template <int DT>
+static int launch_merge_t(const MergeArgs& a, hipStream_t st) {
+    const int heads = a.bsz * a.n_q_heads;
+    if (hipMemsetAsync(a.mask, 0, (size_t)a.bsz * a.q_len * sizeof(int32_t), st) != hipSuccess) return KVC_ERR_HIP;
+    const int64_t n_idx = (int64_t)heads * a.n_keep;
+    hipLaunchKernelGGL(merge_mask_kernel, dim3((unsigned)((n_idx + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(merge_drop_kernel, dim3((unsigned)a.bsz), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL((merge_kept_kernel<DT>), dim3((unsigned)a.rows, (unsigned)heads), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((merge_pivot_kernel<DT>), dim3((unsigned)((a.q_len + 255) / 256), (unsigned)heads), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((merge_reduce_kernel<DT>), dim3((unsigned)a.rows, (unsigned)heads, 2), dim3(64), 0, st, a);
+    return 0;
+}
+
+int launch_merge(const MergeArgs& a, int dtype, hipStream_t st) {
+    switch (dtype) {
+        case KVC_BF16: return launch_merge_t<KVC_BF16>(a, st);
+        case KVC_FP16: return launch_merge_t<KVC_FP16>(a, st);
+    }
+    return KVC_ERR_UNSUPPORTED;
+}
+
+}  // namespace kvc

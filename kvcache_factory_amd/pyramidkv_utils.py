@@ -9,8 +9,8 @@ by one call into the HIP library (include/kvc.h: kvc_compress).  Differences, al
     H_q / H_kv — the outputs are identical ([bsz, H_q, cap, D]); the second form reads each KV head once.
   * the reference prints its budget on every call (pyramidkv_utils.py:217,312,539,601); here that is
     opt-in: set `kvcache_factory_amd.pyramidkv_utils.VERBOSE = True` (or KVC_VERBOSE=1).
-  * `merge` (LOOK-M pivot merge, :119-170) is out of scope: anything but None raises.
-  * L2NormCluster (:394-429) is built; CAM and ThinK are not.
+  * `merge="pivot"` (LOOK-M pivot merge, merge_kv :119-170) and L2NormCluster (:394-429) are built; CAM and
+    ThinK are not.
   * tensors must live on the GPU: there is no CPU / eager fallback.
   * `PrefillBatch` (not in the reference): the patched forwards hand every layer's (K, window-Q, V) to it and every
     GROUP_LAYERS-th layer (and the last) flushes the parked ones through ONE kvc_compress_batch call on a side stream,
@@ -43,10 +43,8 @@ def _say(msg):
 
 
 def _check_merge(merge):
-    if merge is not None:
-        if merge not in ("pivot",):
-            raise ValueError('Merge method not supported')        # pyramidkv_utils.py:164
-        raise NotImplementedError("merge='pivot' (LOOK-M, pyramidkv_utils.py:119-170) is outside this build's scope")
+    if merge is not None and merge not in ("pivot",):
+        raise ValueError('Merge method not supported')            # pyramidkv_utils.py:164
 
 
 def _run(method, key_states, query_states, value_states, window, n_keep, kernel_size, pooling):
@@ -89,6 +87,16 @@ class _KVCluster:
         if q_len < self.max_capacity_prompt:                               # :314 pass-through, same objects
             return key_states, value_states
         _check_merge(self.merge)
+        if self.merge is not None:                                         # :337-339 merge_kv instead of the gather
+            _say("Pivot merge")                                            # :153
+            if head_dim != 128:
+                raise RuntimeError("merge_kv hard-codes head_dim 128 (pyramidkv_utils.py:149)")
+            scoring = self._method != _kvc.STREAMINGLLM
+            if scoring and self._method != _kvc.H2O and self.pooling not in ("avgpool", "maxpool"):
+                raise ValueError('Pooling method not supported')            # :333
+            return _kvc.compress_merge(self._method, query_states if scoring else None, key_states, value_states, self.window_size,
+                                       n_keep, self.kernel_size, self.pooling if self._method != _kvc.H2O else None, TIE_MODE,
+                                       n_q_heads=num_heads)
         if self._method == _kvc.STREAMINGLLM:
             return _kvc.compress(_kvc.STREAMINGLLM, None, key_states, value_states, self.window_size, n_keep,
                                  n_q_heads=num_heads)
@@ -126,8 +134,8 @@ class PrefillBatch:
         alloc(bsz, n_heads, capacity_rows, head_dim, dtype, device) -> (k_buf, v_buf): optional owner-provided output
         buffers (a decode cache with spare rows); K' / V' are then written straight into them and sink gets views."""
         bsz, num_heads, q_len, head_dim = cluster._prefill_shapes(key_states, query_states)
-        if q_len < cluster.max_capacity_prompt or cluster._method in (_kvc.H2O, _kvc.L2NORM):
-            return False
+        if q_len < cluster.max_capacity_prompt or cluster._method in (_kvc.H2O, _kvc.L2NORM) or cluster.merge is not None:
+            return False                                             # (merge_kv takes the direct path: its own kernels)
         n_keep = cluster._budget(q_len)
         _say(f"{cluster._name} max_capacity_prompt {n_keep if cluster._method == _kvc.PYRAMIDKV else cluster.max_capacity_prompt}")
         _check_merge(cluster.merge)

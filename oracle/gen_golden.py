@@ -142,6 +142,53 @@ def run_l2norm_case(c):
     return meta, out
 
 
+def run_merge_case(c):
+    """SnapKV / PyramidKV / H2O with merge="pivot" (merge_kv, pyramidkv_utils.py:119-170, called at :337-339): stored are the topk
+    indices the reference selected, the pivot (argmax) row of every dropped token (captured at its similarity.max call), the number
+    of dropped tokens, and SHA-256 of the merged K / V (+ the tensors themselves for small cases)."""
+    dtype = DT[c["dtype"]]
+    q, k, v = synth.make_qkv(c["Hq"], c["Hkv"], c["L"], c["D"], dtype, c["seed"], peaky=c.get("peaky", False), expanded=True)
+    kw = dict(window_size=c["W"], max_capacity_prompt=c["cap"], kernel_size=c["kernel"], pooling=c["pooling"], merge="pivot")
+    base = c["method"].split("_")[1]
+    if base == "snapkv":
+        cl = ref.SnapKVCluster(**kw)
+    elif base == "pyramidkv":
+        cl = ref.PyramidKVCluster(num_hidden_layers=c["n_layers"], layer_idx=c["layer_idx"], **kw)
+    else:
+        cl = ref.H2OKVCluster(**kw)
+    taps = []
+    orig_max = torch.Tensor.max
+
+    def tmax(t, *a, **kwa):
+        r = orig_max(t, *a, **kwa)
+        if a or kwa:
+            taps.append(r.indices.detach().clone())
+        return r
+    torch.Tensor.max = tmax
+    try:
+        t0 = time.time()
+        with TopkTap() as tap, contextlib.redirect_stdout(io.StringIO()):
+            ko, vo = cl.update_kv(k, q, v, None, c["Hq"] // c["Hkv"])
+        dt = time.time() - t0
+    finally:
+        torch.Tensor.max = orig_max
+    meta = dict(c)
+    meta["ref_seconds"] = round(dt, 4)
+    meta["passthrough"] = bool(ko is k and vo is v)
+    meta["out_shape"] = list(ko.shape)
+    meta["k_out_sha256"], meta["v_out_sha256"] = sha(ko), sha(vo)
+    out = {}
+    if tap.calls:
+        sc, val, idx = tap.calls[0]
+        meta["n_keep"] = int(idx.shape[-1])
+        out["indices"] = idx[0].numpy().astype(np.int64)
+        out["pivot"] = taps[-1][0].numpy().astype(np.int16)
+        meta["drop_len"] = int(taps[-1].shape[-1])
+        if c["L"] <= 1100 or c.get("store_out"):
+            out["k_out"], out["v_out"] = raw_bits(ko[0]), raw_bits(vo[0])
+    return meta, out
+
+
 def make_cluster(c):
     kw = dict(window_size=c["W"], max_capacity_prompt=c["cap"], kernel_size=c["kernel"], pooling=c["pooling"])
     m = c["method"]
@@ -255,6 +302,14 @@ def cases():
     add("adakv_bf16_passthrough", method="adakv", dtype="bf16", Hq=4, Hkv=2, L=60, D=64, W=8, cap=128, kernel=7, pooling="maxpool", floor=0.2, normalize=True)
     add("adakv_8k_bf16", method="adakv", dtype="bf16", Hq=32, Hkv=8, L=8000, D=128, W=8, cap=128, kernel=7, pooling="maxpool", floor=0.2, normalize=True, seed=0)
     add("adakv_8k_bf16_peaky", method="adakv", dtype="bf16", Hq=32, Hkv=8, L=8000, D=128, W=8, cap=128, kernel=7, pooling="maxpool", floor=0.2, normalize=True, seed=1, peaky=True)
+    # ---- merge_kv pivot merge (LOOK-M) behind SnapKV / PyramidKV / H2O ----
+    for dt in ("bf16", "fp16"):
+        add(f"merge_snapkv_{dt}_L600", method="merge_snapkv", dtype=dt, Hq=8, Hkv=2, L=600, D=128, W=8, cap=72, kernel=7, pooling="maxpool")
+        add(f"merge_snapkv_{dt}_W32_L1024", method="merge_snapkv", dtype=dt, Hq=4, Hkv=4, L=1024, D=128, W=32, cap=160, kernel=5, pooling="avgpool")
+    add("merge_pyramidkv_bf16_L1024", method="merge_pyramidkv", dtype="bf16", Hq=8, Hkv=2, L=1024, D=128, W=8, cap=72, kernel=7, pooling="maxpool", layer_idx=15)
+    add("merge_h2o_bf16_L300", method="merge_h2o", dtype="bf16", Hq=4, Hkv=2, L=300, D=128, W=8, cap=48)
+    add("merge_snapkv_bf16_peaky_L1024", method="merge_snapkv", dtype="bf16", Hq=8, Hkv=2, L=1024, D=128, W=8, cap=136, kernel=7, pooling="maxpool", peaky=True)
+    add("merge_snapkv_8k_bf16", method="merge_snapkv", dtype="bf16", Hq=32, Hkv=8, L=8000, D=128, W=8, cap=128, kernel=7, pooling="maxpool", seed=0, store_out=True)
     # ---- L2Norm (smallest key norms, ascending; no window, no query) ----
     for dt in ("bf16", "fp16", "fp32"):
         add(f"l2norm_{dt}_L600", method="l2norm", layer_idx=5, dtype=dt, Hq=8, Hkv=2, L=600, D=128, cap=96)
@@ -286,6 +341,8 @@ def main():
             meta, arrays = run_ragged_case(c)
         elif c["method"] == "l2norm":
             meta, arrays = run_l2norm_case(c)
+        elif c["method"].startswith("merge_"):
+            meta, arrays = run_merge_case(c)
         else:
             meta, arrays = run_case(c, store_scores=small)
         manifest[c["name"]] = meta

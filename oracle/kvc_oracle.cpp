@@ -607,6 +607,119 @@ KVCO_API int kvco_l2norm(const kvco_params* P, const void* k, const void* v, voi
     return 0;
 }
 
+// ----------------------------------------------------------------------------------------
+// merge_kv(..., merge="pivot") (pyramidkv_utils.py:119-170, LOOK-M) — called by SnapKV / PyramidKV / H2O update_kv
+// right after their .topk when the cluster was built with merge="pivot" (:337-339): instead of dropping the unselected
+// tokens, every dropped key is averaged into the kept key it is most similar to (cosine), and its value into the value row of
+// the same number.  Restated with the reference's quirks, which parity must reproduce:
+//   * "dropped" = positions selected by NO head (torch.isin against the indices of ALL heads flattened, :131-134), the last
+//     window_size positions included; the same drop list for every head;
+//   * the kept keys are ordered [window rows, selected rows] (:145) but the kept values [selected rows, window rows] (:147),
+//     and the pivot index found on the keys is used for both (:155-160);
+//   * head_dim is hard-coded as 128 (:149, :154).
+// Arithmetic (16-bit dtypes), each step checked against torch in this container:
+//   norms: torch.norm's 8-accumulator order (see kvco_l2norm);  x / norm: fp32 divide, one rounding;
+//   similarity = normalised_dropped @ normalised_kept^T: torch's reduced-precision GEMM accumulates in fp32 in an order that is
+//     not documented; restated as the d-ascending fp32 sum of the (exact) products, rounded once — on 230 400 entries 10
+//     differed from torch (0.004 %) and no argmax moved; at the 8k configuration a handful of dropped tokens may pick a
+//     different pivot than the reference (measured by the fixtures);
+//   max(dim=-1): the FIRST maximal column;  merged = ((dropped + kept[pivot]) -> dtype) / 2;
+//   scatter_reduce(mean, include_self=True): fp32 sum of the row itself and its merged rows in ascending dropped position,
+//     rounded to the dtype; the count (1 + contributions) rounded to the dtype; their quotient rounded to the dtype.
+// ----------------------------------------------------------------------------------------
+template <class DT>
+static float norm8(const typename DT::raw* row, int D) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int d = 0; d < D; ++d) { const float x = DT::ld(row[d]); acc[d & 7] = acc[d & 7] + x * x; }
+    float tot = acc[0];
+    for (int j = 1; j < 8; ++j) tot = tot + acc[j];
+    return rnd<DT>(std::sqrt(tot));
+}
+template <class DT>
+static int merge_pivot_impl(const kvco_params& P, const void* k_, const void* v_, const int64_t* idx, void* k_out_, void* v_out_,
+                            int32_t* pivot_out, int64_t* drop_len_out) {
+    typedef typename DT::raw raw;
+    const int H = P.n_q_heads, G = H / P.n_kv_heads, D = P.head_dim, W = P.window;
+    const int64_t L = P.q_len, kk = P.k, R = kk + W;
+    std::vector<char> selected((size_t)L, 0);
+    for (int64_t i = 0; i < (int64_t)H * kk; ++i) selected[(size_t)idx[i]] = 1;
+    std::vector<int64_t> drop;
+    for (int64_t j = 0; j < L; ++j) if (!selected[(size_t)j]) drop.push_back(j);
+    const int64_t M = (int64_t)drop.size();
+    if (drop_len_out) *drop_len_out = M;
+    int err = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int h = 0; h < H; ++h) {
+        const raw* kh = (const raw*)k_ + (int64_t)(h / G) * P.k_stride_h;
+        const raw* vh = (const raw*)v_ + (int64_t)(h / G) * P.v_stride_h;
+        // kept rows: source position of row r in the KEY order [window, selected] and in the VALUE order [selected, window]
+        std::vector<int64_t> kpos((size_t)R), vpos((size_t)R);
+        for (int64_t r = 0; r < R; ++r) {
+            kpos[(size_t)r] = r < W ? L - W + r : idx[(int64_t)h * kk + (r - W)];
+            vpos[(size_t)r] = r < kk ? idx[(int64_t)h * kk + r] : L - W + (r - kk);
+        }
+        std::vector<float> kn((size_t)R * D);                                       // normalised kept keys (dtype values)
+        for (int64_t r = 0; r < R; ++r) {
+            const raw* row = kh + kpos[(size_t)r] * P.k_stride_l;
+            const float n = norm8<DT>(row, D);
+            for (int d = 0; d < D; ++d) kn[(size_t)r * D + d] = rnd<DT>(DT::ld(row[d]) / n);
+        }
+        std::vector<float> ksum((size_t)R * D), vsum((size_t)R * D);
+        std::vector<int64_t> cnt((size_t)R, 1);
+        for (int64_t r = 0; r < R; ++r)
+            for (int d = 0; d < D; ++d) {
+                ksum[(size_t)r * D + d] = DT::ld(kh[kpos[(size_t)r] * P.k_stride_l + d]);
+                vsum[(size_t)r * D + d] = DT::ld(vh[vpos[(size_t)r] * P.v_stride_l + d]);
+            }
+        std::vector<float> a((size_t)D);
+        for (int64_t p = 0; p < M; ++p) {
+            const raw* krow = kh + drop[(size_t)p] * P.k_stride_l;
+            const raw* vrow = vh + drop[(size_t)p] * P.v_stride_l;
+            const float n = norm8<DT>(krow, D);
+            for (int d = 0; d < D; ++d) a[(size_t)d] = rnd<DT>(DT::ld(krow[d]) / n);
+            int64_t best = 0; float bestv = 0.0f;
+            for (int64_t r = 0; r < R; ++r) {
+                float s = 0.0f;
+                for (int d = 0; d < D; ++d) s = s + a[(size_t)d] * kn[(size_t)r * D + d];
+                s = rnd<DT>(s);
+                if (r == 0 || s > bestv) { best = r; bestv = s; }
+            }
+            if (pivot_out) pivot_out[(int64_t)h * M + p] = (int32_t)best;
+            const raw* ksel = kh + kpos[(size_t)best] * P.k_stride_l;
+            const raw* vsel = vh + vpos[(size_t)best] * P.v_stride_l;
+            for (int d = 0; d < D; ++d) {
+                const float km = rnd<DT>(rnd<DT>(DT::ld(krow[d]) + DT::ld(ksel[d])) / 2.0f);
+                const float vm = rnd<DT>(rnd<DT>(DT::ld(vrow[d]) + DT::ld(vsel[d])) / 2.0f);
+                ksum[(size_t)best * D + d] = ksum[(size_t)best * D + d] + km;
+                vsum[(size_t)best * D + d] = vsum[(size_t)best * D + d] + vm;
+            }
+            cnt[(size_t)best]++;
+        }
+        raw* ko = (raw*)k_out_ + (int64_t)h * R * D;
+        raw* vo = (raw*)v_out_ + (int64_t)h * R * D;
+        for (int64_t r = 0; r < R; ++r) {
+            const float c = rnd<DT>((float)cnt[(size_t)r]);
+            for (int d = 0; d < D; ++d) {
+                ko[r * D + d] = DT::st(rnd<DT>(ksum[(size_t)r * D + d]) / c);
+                vo[r * D + d] = DT::st(rnd<DT>(vsum[(size_t)r * D + d]) / c);
+            }
+        }
+    }
+    return err;
+}
+// idx: [H][P->k] int64, the indices the method's .topk returned.  k_out / v_out: [H][k + window][D].  pivot_out (optional):
+// [H][drop_len] int32, drop_len returned through drop_len_out (size the buffer for q_len).
+KVCO_API int kvco_merge_pivot(const kvco_params* P, const void* k, const void* v, const int64_t* idx, void* k_out, void* v_out,
+                              int32_t* pivot_out, int64_t* drop_len_out) {
+    if (int e = check(*P)) return e;
+    if (P->head_dim != 128) return -4;                                            // the reference hard-codes 128 (:149)
+    switch (P->dtype) {
+        case KVCO_BF16: return merge_pivot_impl<DtBf16>(*P, k, v, idx, k_out, v_out, pivot_out, drop_len_out);
+        case KVCO_FP16: return merge_pivot_impl<DtFp16>(*P, k, v, idx, k_out, v_out, pivot_out, drop_len_out);
+        default: return -4;                                                      // fp32: torch's fp32 GEMM / norm orders not restated
+    }
+}
+
 // Scalar probes used by tests to pin the helper arithmetic.
 KVCO_API float kvco_exp_u20(float x) { return exp_u20(x); }
 KVCO_API float kvco_sum(const float* x, int64_t n, int sum_mode) {

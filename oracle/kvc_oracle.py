@@ -60,6 +60,7 @@ def lib():
         L.kvco_adakv_caps.argtypes = [pp, vp, ctypes.c_int64, ctypes.c_double, ctypes.c_int, vp]
         L.kvco_ragged_gather.argtypes = [pp, vp, ctypes.c_int64, ctypes.c_int64, i64p, vp, vp]
         L.kvco_l2norm.argtypes = [pp, vp, vp, vp, i64p, vp, vp]
+        L.kvco_merge_pivot.argtypes = [pp, vp, vp, i64p, vp, vp, vp, vp]
         L.kvco_pyramid_k.argtypes = [ctypes.c_int64] * 6
         L.kvco_pyramid_k.restype = ctypes.c_int64
         L.kvco_exp_u20.argtypes = [ctypes.c_float]
@@ -205,6 +206,30 @@ def ragged(q, k, v, window, max_capacity_prompt, kernel_size=7, pooling="maxpool
     _rc(lib().kvco_ragged_gather(ctypes.byref(p), _ptr(k), k.stride(1), k.stride(2), _ptr(idx), _ptr(caps), _ptr(kf)), "ragged_gather")
     _rc(lib().kvco_ragged_gather(ctypes.byref(p), _ptr(v), v.stride(1), v.stride(2), _ptr(idx), _ptr(caps), _ptr(vf)), "ragged_gather")
     return kf, vf, lens.to(torch.int32), caps, idx, sc
+
+
+def merge_pivot(k, v, idx, window, n_threads=0):
+    """merge_kv(key_states, value_states, indices, window_size, "pivot") (pyramidkv_utils.py:119-170) for idx [Hq, n_keep] int64
+    (the method's topk indices).  Returns (k_out [1, Hq, n_keep + W, D] in the order [window, selected], v_out in the order
+    [selected, window], pivot int32 [Hq, drop_len])."""
+    _check_inner(k), _check_inner(v)
+    assert idx.dim() == 2 and idx.is_contiguous() and idx.dtype == torch.int64
+    p = Params()
+    p.dtype = _DTYPE[k.dtype]
+    p.n_q_heads, p.n_kv_heads = idx.shape[0], k.shape[1]
+    p.q_len, p.head_dim = k.shape[2], k.shape[3]
+    p.window, p.k, p.n_threads = window, idx.shape[1], n_threads
+    p.kernel_size, p.pooling = 1, _POOL["maxpool"]
+    p.k_stride_h, p.k_stride_l = k.stride(1), k.stride(2)
+    p.v_stride_h, p.v_stride_l = v.stride(1), v.stride(2)
+    H, R, D = idx.shape[0], idx.shape[1] + window, k.shape[3]
+    ko = torch.empty(1, H, R, D, dtype=k.dtype)
+    vo = torch.empty_like(ko)
+    pivot = torch.empty(H, k.shape[2], dtype=torch.int32)
+    dl = ctypes.c_int64(0)
+    _rc(lib().kvco_merge_pivot(ctypes.byref(p), _ptr(k), _ptr(v), _ptr(idx), _ptr(ko), _ptr(vo), _ptr(pivot), ctypes.byref(dl)), "merge_pivot")
+    M = int(dl.value)
+    return ko, vo, pivot.view(-1)[: H * M].view(H, M).clone()
 
 
 def l2norm(k, v, max_capacity_prompt, n_q_heads, n_threads=0):

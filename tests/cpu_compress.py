@@ -59,3 +59,18 @@ def oracle_l2norm_compress(k, v, rows, n_q_heads=None, return_indices=False, ret
     if return_norms:
         res.append(norms[None])
     return tuple(res)
+
+
+def oracle_compress_merge(method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu", n_q_heads=None):
+    """Stand-in for _kvc.compress_merge (host-logic tests only)."""
+    assert k.shape[0] == 1
+    k, v = k.contiguous(), v.contiguous()
+    if method == _kvc.STREAMINGLLM:
+        hq = n_q_heads if n_q_heads is not None else k.shape[1]
+        idx = torch.arange(n_keep, dtype=torch.int64).expand(hq, n_keep).contiguous()
+    else:
+        sc = O.scores(q, k, window, kernel_size, pooling if method != _kvc.H2O else "avgpool", full_rows=method == _kvc.H2O,
+                      dot_mode=O.DOT_CHAIN, sum_mode=O.SUM_TORCH16)
+        idx, _ = O.topk(sc, n_keep, O.TIES_TORCH if tie_mode in ("torch_cpu", 0) else O.TIES_CANON)
+    ko, vo, _ = O.merge_pivot(k, v, idx, window)
+    return ko, vo

@@ -1093,3 +1093,64 @@ def test_l2norm_patched_model_on_gpu(kvc, oracle, gpu_device):
         assert torch.equal(G.bits(kc.cpu()), G.bits(ko_o)) and torch.equal(G.bits(vc.cpu()), G.bits(vo_o))
         assert torch.equal(G.bits(cache.layers[li].keys[:, :, :cap].cpu()), G.bits(ko_o))
     assert out.sequences.shape[1] == L + 4
+
+
+MERGE = lambda m: m["method"].startswith("merge_")          # noqa: E731
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", G.names(MERGE))
+def test_merge_pivot_vs_reference(kvc, gpu_device, name):
+    """SURVEY 8f N4, merge_kv(..., "pivot") (pyramidkv_utils.py:119-170) through kvc_merge_pivot, fed the reference's own topk
+    indices: the pivot of every dropped token equals the one captured at the reference's similarity.max (first maximum of the
+    dtype-rounded cosine), and the merged K' (rows [window, selected]) and V' (rows [selected, window]) equal the reference's bytes
+    (SHA-256) — at 8k -> 128 with 32 heads too.  K, V in the expanded form and GQA-native; once into a caller's buffers."""
+    m = G.MANIFEST[name]
+    a = G.arrays(name)
+    q, k, v = G.inputs(m)
+    g = m["Hq"] // m["Hkv"]
+    idx = torch.from_numpy(a["indices"])[None].contiguous().to(gpu_device)
+    method = {"snapkv": kvc.SNAPKV, "pyramidkv": kvc.PYRAMIDKV, "h2o": kvc.H2O}[m["method"].split("_")[1]]
+    want_piv = torch.from_numpy(a["pivot"].astype("int32"))
+    R = m["n_keep"] + m["W"]
+    for i, (kk, vv) in enumerate(((k, v), (k[:, ::g].contiguous(), v[:, ::g].contiguous()))):
+        out = None
+        if i == 1:
+            out = (torch.zeros(1, m["Hq"], R + 3, 128, dtype=k.dtype, device=gpu_device), torch.zeros(1, m["Hq"], R + 3, 128, dtype=k.dtype, device=gpu_device))
+        ko, vo, piv = kvc.merge_pivot(method, kk.to(gpu_device), vv.to(gpu_device), idx, m["W"], return_pivot=True, out=out)
+        assert piv.shape[2] == m["drop_len"]
+        assert torch.equal(piv[0].cpu(), want_piv)
+        assert G.sha(ko.cpu().contiguous()) == m["k_out_sha256"] and G.sha(vo.cpu().contiguous()) == m["v_out_sha256"]
+        if out is not None:
+            assert float(out[0][:, :, R:].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["merge_snapkv_bf16_L600", "merge_snapkv_fp16_W32_L1024", "merge_pyramidkv_bf16_L1024", "merge_h2o_bf16_L300",
+                                  "merge_snapkv_8k_bf16"])
+def test_cluster_with_pivot_merge_on_gpu(kvc, gpu_device, name):
+    """The cluster classes built with merge="pivot" on the GPU: scoring, the exact-tie top-k and merge_kv all in the library;
+    update_kv returns the reference's merged K / V (SHA-256)."""
+    from kvcache_factory_amd import pyramidkv_utils as pu
+    m = G.MANIFEST[name]
+    q, k, v = G.inputs(m)
+    kw = dict(window_size=m["W"], max_capacity_prompt=m["cap"], kernel_size=m["kernel"], pooling=m["pooling"], merge="pivot")
+    base = m["method"].split("_")[1]
+    cls = {"snapkv": pu.SnapKVCluster, "h2o": pu.H2OKVCluster,
+           "pyramidkv": lambda **a: pu.PyramidKVCluster(num_hidden_layers=m["n_layers"], layer_idx=m["layer_idx"], **a)}[base]
+    g = m["Hq"] // m["Hkv"]
+    ko, vo = cls(**kw).update_kv(k[:, ::g].contiguous().to(gpu_device), q.to(gpu_device), v[:, ::g].contiguous().to(gpu_device), None, g)
+    assert list(ko.shape) == m["out_shape"]
+    assert G.sha(ko.cpu().contiguous()) == m["k_out_sha256"] and G.sha(vo.cpu().contiguous()) == m["v_out_sha256"]
+
+
+@pytest.mark.gpu
+def test_streamingllm_with_pivot_merge_on_gpu(kvc, oracle, gpu_device):
+    """StreamingLLM + merge="pivot" (pyramidkv_utils.py:610-614): the first n_keep positions are "selected" for every head."""
+    from kvcache_factory_amd import pyramidkv_utils as pu
+    q, k, v = G.synth.make_qkv(8, 2, 700, 128, torch.bfloat16, 4242)
+    ko, vo = pu.StreamingLLMKVCluster(window_size=16, max_capacity_prompt=80, merge="pivot").update_kv(
+        k.to(gpu_device), q.to(gpu_device), v.to(gpu_device), None, 4)
+    idx = torch.arange(64, dtype=torch.int64).expand(8, 64).contiguous()
+    ko_o, vo_o, _ = oracle.merge_pivot(k, v, idx, 16)
+    assert torch.equal(G.bits(ko.cpu()), G.bits(ko_o)) and torch.equal(G.bits(vo.cpu()), G.bits(vo_o))

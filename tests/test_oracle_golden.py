@@ -197,3 +197,17 @@ def test_l2norm_against_reference(oracle, name):
         for h in range(m["Hq"]):
             if bool(same[h]):
                 assert torch.equal(idx[h], want[h])
+
+
+@pytest.mark.parametrize("name", G.names(lambda m: m["method"].startswith("merge_")))
+def test_merge_pivot_against_reference(oracle, name):
+    """SURVEY 8f N4, merge_kv(..., "pivot") (pyramidkv_utils.py:119-170): the oracle's restatement fed the reference's own topk
+    indices — number of dropped tokens, the pivot of every dropped token (captured at the reference's similarity.max), and the
+    merged K / V bit for bit (SHA-256), at 8k -> 128 with 32 heads too (159 168 pivots)."""
+    m = G.MANIFEST[name]
+    a = G.arrays(name)
+    q, k, v = G.inputs(m)
+    ko, vo, piv = oracle.merge_pivot(k, v, torch.from_numpy(a["indices"]).contiguous(), m["W"])
+    assert piv.shape[1] == m["drop_len"]
+    assert torch.equal(piv, torch.from_numpy(a["pivot"].astype("int32")))
+    assert G.sha(ko) == m["k_out_sha256"] and G.sha(vo) == m["v_out_sha256"]

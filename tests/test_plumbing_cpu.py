@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import golden_util as G
-from cpu_compress import oracle_compress, oracle_compress_batch, oracle_l2norm_compress
+from cpu_compress import oracle_compress, oracle_compress_batch, oracle_compress_merge, oracle_l2norm_compress
 from kvcache_factory_amd import _kvc, monkeypatch as mp, pyramidkv_utils as pu
 
 
@@ -17,6 +17,7 @@ def cpu_backend(monkeypatch, oracle):
     monkeypatch.setattr(_kvc, "compress", oracle_compress)
     monkeypatch.setattr(_kvc, "compress_batch", oracle_compress_batch)
     monkeypatch.setattr(_kvc, "l2norm_compress", oracle_l2norm_compress)
+    monkeypatch.setattr(_kvc, "compress_merge", oracle_compress_merge)
     monkeypatch.setattr(pu, "BATCH_LAYERS", False)       # these tests watch one update_kv per layer
     yield
 
@@ -55,7 +56,7 @@ def test_cluster_errors_match_reference(cpu_backend):
         pu.SnapKVCluster(8, 40, pooling="median").update_kv(k, q, v, None, 1)   # :333
     with pytest.raises(ValueError, match="Merge method not supported"):
         pu.SnapKVCluster(8, 40, merge="bogus").update_kv(k, q, v, None, 1)      # :164
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="head_dim 128"):                  # merge_kv hard-codes 128 (:149); these tensors have 64
         pu.SnapKVCluster(8, 40, merge="pivot").update_kv(k, q, v, None, 1)
     # H2O ignores pooling entirely (:555-561)
     ko, vo = pu.H2OKVCluster(8, 40, pooling="median").update_kv(k, q, v, None, 1)
@@ -451,3 +452,20 @@ def test_l2norm_through_the_model(cpu_backend):
         assert cache.get_seq_length() == 96 + 2
     finally:
         mp.replace_llama("fullkv")
+
+
+@pytest.mark.parametrize("name", ["merge_snapkv_bf16_L600", "merge_snapkv_fp16_W32_L1024", "merge_pyramidkv_bf16_L1024", "merge_h2o_bf16_L300"])
+def test_cluster_with_pivot_merge_matches_reference_fixture(cpu_backend, name):
+    """Clusters built with merge="pivot" (merge_kv, pyramidkv_utils.py:119-170 behind :337-339): update_kv returns the merged K / V
+    of the reference — key rows [window, selected], value rows [selected, window] — for the expanded and the GQA-native K/V."""
+    m = G.MANIFEST[name]
+    q, k, v = G.inputs(m)
+    kw = dict(window_size=m["W"], max_capacity_prompt=m["cap"], kernel_size=m["kernel"], pooling=m["pooling"], merge="pivot")
+    base = m["method"].split("_")[1]
+    cls = {"snapkv": pu.SnapKVCluster, "h2o": pu.H2OKVCluster,
+           "pyramidkv": lambda **a: pu.PyramidKVCluster(num_hidden_layers=m["n_layers"], layer_idx=m["layer_idx"], **a)}[base]
+    g = m["Hq"] // m["Hkv"]
+    for kk, vv in ((k, v), (k[:, ::g].contiguous(), v[:, ::g].contiguous())):
+        ko, vo = cls(**kw).update_kv(kk, q, vv, None, g)
+        assert list(ko.shape) == m["out_shape"]
+        assert G.sha(ko) == m["k_out_sha256"] and G.sha(vo) == m["v_out_sha256"]
