@@ -12,15 +12,15 @@
 //   merge_mask_kernel     every selected index marks its position                                  (H_q * k threads)
 //   merge_drop_kernel     ordered compaction of the unmarked positions -> drop[], drop_len          (one workgroup per batch row)
 //   merge_kept_kernel     the normalised kept keys of every head, fp32 in the workspace             (one wave per row)
-//   merge_pivot_kernel    one thread per (head, dropped token): its normalised key in registers, the kept keys 64 rows at a
-//                         time through LDS (broadcast reads), a d-ascending fp32 FMA chain per pair (products of two 16-bit
-//                         values are exact in fp32, so the fused chain IS the sum of products), rounded to the dtype, first maximum
+//   merge_pivot_kernel    the cosines on the f32 MFMA (32 dropped tokens per wave x 128 kept rows per LDS stage; 64
+//                         v_mfma_f32_32x32x2_f32 per block = the d-ascending fp32 chain: products of two 16-bit values are exact
+//                         in fp32), rounded to the dtype, first maximum
 //   merge_reduce_kernel   one wave per (head, kept row, K|V): walks the pivots 64 at a time (ballot -> ascending order), adds the
 //                         merged rows in fp32, then sum -> dtype, count -> dtype, quotient -> dtype
 // Arithmetic = oracle/kvc_oracle.cpp kvco_merge_pivot (norms in torch's 8-accumulator order, fp32 divides, one rounding each),
 // which equals the imported reference bit for bit on every fixture (tests/golden/merge_*).
-// Cost: the pivot stage is H_q * drop_len * (k + W) * D multiply-adds (4.2 G at 8k -> 128) on the fp32 VALU; everything else is
-// small.  The K scan of the scoring stage is unchanged.
+// Cost: the pivot stage is H_q * drop_len * (k + W) * D multiply-adds (4.2 G at 8k -> 128) at the f32 MFMA rate (157 TFLOP/s peak;
+// a scalar-FMA version with the kept rows broadcast from LDS ran at 43 TFLOP/s, 194 us); everything else is small.  The K scan of the scoring stage is unchanged.
 #include "kvc_common.h"
 #include "kvc_launch.h"
 
@@ -108,73 +108,95 @@ __global__ __launch_bounds__(64) void merge_kept_kernel(const MergeArgs a) {
     reinterpret_cast<float2*>(a.kn + (hb * a.rows + r) * 128)[lane] = o;
 }
 
-// grid = (ceil(q_len / 256), bsz * H_q), block = 256: pivot[hb][p] for p < drop_len[b]
+// grid = (ceil(q_len / 128), bsz * H_q), block = 256 = 4 waves: pivot[hb][p] for p < drop_len[b].
+// Each wave owns 32 dropped tokens (the B operand of v_mfma_f32_32x32x2_f32: lane (kh, j) keeps the elements d = 2s + kh of
+// its token j, normalised, in 64 registers); the kept rows are the A operand, 128 rows at a time through LDS (de-interleaved:
+// [row][kh][s], so that four steps of a lane are one 16-byte read).  64 MFMAs per 32 x 32 block of cosines = the d-ascending
+// fp32 chain (each MFMA adds its two products in k order; products of two 16-bit values are exact in fp32), at twice the
+// rate of the scalar FMA; the first maximum over the kept rows is taken with an explicit (value, smaller row) rule.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MP_PITCH = 132;                              // floats per kept row in LDS (16-byte reads of a quarter wave: all banks)
 template <int DT>
 __global__ __launch_bounds__(256) void merge_pivot_kernel(const MergeArgs a) {
-    __shared__ __attribute__((aligned(16))) float tile[64 * 128];                           // 64 kept rows at a time (32 KB)
     typedef typename Dt<DT>::raw raw;
-    const int tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float kept[];                            // [128][MP_PITCH]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kh = lane >> 5, j = lane & 31;
     const int64_t hb = blockIdx.y;
     const int b = (int)(hb / a.n_q_heads), h = (int)(hb % a.n_q_heads);
     const int M = a.drop_len[b];
-    const int p0 = blockIdx.x * 256;
-    if (p0 >= M) return;                                                                    // uniform per workgroup
-    const int p = p0 + tid;
+    if ((int)blockIdx.x * 128 >= M) return;                                                 // uniform per workgroup
+    const int p = blockIdx.x * 128 + wave * 32 + j;
     const bool live = p < M;
-    float x[128];
+    float breg[64];
     {
         const int64_t pos = live ? a.drop[(int64_t)b * a.q_len + p] : 0;
         const raw* row = reinterpret_cast<const raw*>(a.k) + (int64_t)b * a.k_stride_b + (int64_t)(h / a.group) * a.k_stride_h + pos * a.k_stride_l;
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+        float acc4[4] = {0.0f, 0.0f, 0.0f, 0.0f};                                          // accumulators 2i + kh of torch's eight
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const uint4 v = reinterpret_cast<const uint4*>(row)[c];
             const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float e0 = Dt<DT>::ld((raw)(wv[j] & 0xffffu)), e1 = Dt<DT>::ld((raw)(wv[j] >> 16));
-                x[8 * c + 2 * j] = e0;
-                x[8 * c + 2 * j + 1] = e1;
-                acc[2 * j] = acc[2 * j] + e0 * e0;
-                acc[2 * j + 1] = acc[2 * j + 1] + e1 * e1;
+            for (int i = 0; i < 4; ++i) {                                                   // elements 8c + 2i + kh
+                const float e = Dt<DT>::ld((raw)(kh ? (wv[i] >> 16) : (wv[i] & 0xffffu)));
+                breg[4 * c + i] = e;
+                acc4[i] = acc4[i] + e * e;
             }
         }
-        float tot = acc[0];
+        float oth[4];
 #pragma unroll
-        for (int j = 1; j < 8; ++j) tot = tot + acc[j];
+        for (int i = 0; i < 4; ++i) oth[i] = xor_lane<32>(acc4[i]);
+        float tot = kh ? oth[0] : acc4[0];                                                  // accumulators 0..7 in order
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float ev = kh ? oth[i] : acc4[i], od = kh ? acc4[i] : oth[i];
+            if (i > 0) tot = tot + ev;
+            tot = tot + od;
+        }
         const float n = rnd<DT>(__builtin_sqrtf(tot));
 #pragma unroll
-        for (int d = 0; d < 128; ++d) x[d] = rnd<DT>(x[d] / n);
+        for (int s_ = 0; s_ < 64; ++s_) breg[s_] = rnd<DT>(breg[s_] / n);
     }
-    int best = 0;
     float bestv = 0.0f;
-    // (Measured alternatives: the kept rows through the scalar cache as SGPR operands — 482 us, the scalar cache cannot feed
-    // 4 096 waves; two rows per packed-fp32 FMA with the dropped row duplicated in register pairs — spills to AGPRs.)
+    int best = 0x7fffffff;
     const float* kn = a.kn + hb * a.rows * 128;
-    for (int r0 = 0; r0 < a.rows; r0 += 64) {
-        const int nr = a.rows - r0 < 64 ? a.rows - r0 : 64;
+    for (int r0 = 0; r0 < a.rows; r0 += 128) {
+        const int nr = a.rows - r0 < 128 ? a.rows - r0 : 128;
         __syncthreads();
-        for (int i = tid; i < nr * 32; i += 256)
-            reinterpret_cast<float4*>(tile)[i] = reinterpret_cast<const float4*>(kn + (int64_t)r0 * 128)[i];
+        for (int i = tid; i < 128 * 32; i += 256) {                                         // (row, 4 consecutive d) -> evens | odds
+            const int row = i >> 5, c = i & 31;
+            const float4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+            const float4 u = row < nr ? reinterpret_cast<const float4*>(kn + (int64_t)(r0 + row) * 128)[c] : z;
+            *reinterpret_cast<float2*>(kept + row * MP_PITCH + 2 * c) = float2{u.x, u.z};
+            *reinterpret_cast<float2*>(kept + row * MP_PITCH + 64 + 2 * c) = float2{u.y, u.w};
+        }
         __syncthreads();
-        for (int r = 0; r < nr; ++r) {
-            const float4* t4 = reinterpret_cast<const float4*>(tile + r * 128);
-            float s = 0.0f;
+        const int n_mt = (nr + 31) >> 5;
+        for (int mt = 0; mt < n_mt; ++mt) {
+            const float* arow = kept + (mt * 32 + j) * MP_PITCH + kh * 64;
+            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int c = 0; c < 32; ++c) {
-                const float4 t = t4[c];
-                s = __builtin_fmaf(x[4 * c], t.x, s);
-                s = __builtin_fmaf(x[4 * c + 1], t.y, s);
-                s = __builtin_fmaf(x[4 * c + 2], t.z, s);
-                s = __builtin_fmaf(x[4 * c + 3], t.w, s);
+            for (int g = 0; g < 16; ++g) {
+                const float4 av = *reinterpret_cast<const float4*>(arow + 4 * g);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, breg[4 * g], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, breg[4 * g + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, breg[4 * g + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, breg[4 * g + 3], acc, 0, 0, 0);
             }
-            s = rnd<DT>(s);
-            if ((r0 + r == 0) || s > bestv) { best = r0 + r; bestv = s; }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = r0 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                const float v = rnd<DT>(acc[e]);
+                if (r < a.rows && (best == 0x7fffffff || v > bestv || (v == bestv && r < best))) { best = r; bestv = v; }
+            }
         }
     }
-    if (live) a.pivot[hb * a.q_len + p] = best;
+    {   // the two half-waves hold different kept rows of the same token: first maximum of the pair
+        const float ov = xor_lane<32>(bestv);
+        const int orow = __float_as_int(xor_lane<32>(__int_as_float(best)));
+        if (orow != 0x7fffffff && (best == 0x7fffffff || ov > bestv || (ov == bestv && orow < best))) { best = orow; bestv = ov; }
+    }
+    if (live && kh == 0) a.pivot[hb * a.q_len + p] = best;
 }
 
 // grid = (R, bsz * H_q, 2 {K, V}), block = 64: one kept row; lane l holds elements 2l, 2l + 1
@@ -225,7 +247,10 @@ static int launch_merge_t(const MergeArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(merge_mask_kernel, dim3((unsigned)((n_idx + 255) / 256)), dim3(256), 0, st, a);
     hipLaunchKernelGGL(merge_drop_kernel, dim3((unsigned)a.bsz), dim3(1024), 0, st, a);
     hipLaunchKernelGGL((merge_kept_kernel<DT>), dim3((unsigned)a.rows, (unsigned)heads), dim3(64), 0, st, a);
-    hipLaunchKernelGGL((merge_pivot_kernel<DT>), dim3((unsigned)((a.q_len + 255) / 256), (unsigned)heads), dim3(256), 0, st, a);
+    static LdsCache lds_cache = {};
+    const size_t lds = (size_t)128 * MP_PITCH * sizeof(float);
+    if (ensure_lds(reinterpret_cast<const void*>(&merge_pivot_kernel<DT>), lds, lds_cache) != 0) return KVC_ERR_HIP;
+    hipLaunchKernelGGL((merge_pivot_kernel<DT>), dim3((unsigned)((a.q_len + 127) / 128), (unsigned)heads), dim3(256), lds, st, a);
     hipLaunchKernelGGL((merge_reduce_kernel<DT>), dim3((unsigned)a.rows, (unsigned)heads, 2), dim3(64), 0, st, a);
     return 0;
 }
