@@ -266,6 +266,24 @@ size_t kvc_merge_workspace_bytes(const kvc_params* p);
 int kvc_merge_pivot(const kvc_params* p, const void* k, const void* v, const int64_t* idx, void* k_out, void* v_out,
                     int32_t* pivot_out, int32_t* drop_len_out, void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* ---- ThinK channel pruning, key_pruner_query_driven (pyramidkv_utils.py:13-26) ---------------------------
+ * What SnapKVCluster.update_think (:349-392) does after its compression: per head the n_prune = int(head_dim * ratio) channels
+ * with the smallest mean(q^2 over the last 32 query rows) * mean(k'^2 over the compressed keys) are removed from the compressed
+ * keys except the last `recent` rows.  kc: the compressed keys [b*n_heads][rows][head_dim] (rows dense, kc_stride_h elements
+ * between heads — kvc_compress's k_out with its out_stride_h); q: the prompt's queries, rows q_len-32 .. q_len-1 are read.
+ * Outputs: pruned [b*n_heads][rows - recent][head_dim - n_prune] (kept channels in order), keep [b*n_heads][head_dim] bytes
+ * (1 = kept: the reference's returned ~mask), channel_scores [b*n_heads][head_dim] dtype or NULL.  The recent rows stay where
+ * they are (kc rows rows-recent ..).  head_dim 64 or 128, q_len >= 32.  Same arithmetic and tie order as torch-CPU
+ * (csrc/kvc_think.hip).  No workspace. */
+typedef struct kvc_think_params {
+    int32_t dtype, bsz, n_heads, q_len, head_dim;
+    int32_t rows, recent, n_prune;
+    int64_t q_stride_b, q_stride_h, q_stride_l;     /* elements */
+    int64_t kc_stride_h;                            /* elements between heads of kc (>= rows * head_dim) */
+} kvc_think_params;
+int kvc_think_prune(const kvc_think_params* p, const void* q, const void* kc, void* pruned, uint8_t* keep, void* channel_scores,
+                    void* hip_stream);
+
 /* Debug/parity aid: byte offsets inside the workspace of the intermediates kvc_scores leaves behind.
  * offs[0]=logits [b][h][L][W] dtype, offs[1]=row max [b][h][W] f32, offs[2]=row sum [b][h][W] f32.
  * Returns KVC_OK or an error. */

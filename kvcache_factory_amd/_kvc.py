@@ -25,7 +25,7 @@ EXPORTS = ("kvc_version", "kvc_last_error", "kvc_workspace_bytes", "kvc_compress
            "kvc_gather", "kvc_pyramid_k", "kvc_workspace_layout", "kvc_workspace_bytes_batch", "kvc_compress_batch",
            "kvc_select_workspace_bytes", "kvc_decode_step", "kvc_ragged_workspace_bytes", "kvc_ragged_plan",
            "kvc_ragged_compact", "kvc_ragged_decode_step", "kvc_l2norm_workspace_bytes", "kvc_l2norm_compress",
-           "kvc_merge_workspace_bytes", "kvc_merge_pivot")
+           "kvc_merge_workspace_bytes", "kvc_merge_pivot", "kvc_think_prune")
 
 
 class KvcError(RuntimeError):
@@ -49,6 +49,11 @@ class DecodeParams(ctypes.Structure):
         (n, ctypes.c_int64) for n in ("q_stride_b", "q_stride_h", "q_stride_l", "new_stride_b", "new_stride_h", "new_stride_l",
                                       "prefix_stride_b", "prefix_stride_h", "tail_stride_b", "tail_stride_h",
                                       "out_stride_b", "out_stride_h", "out_stride_l")]
+
+
+class ThinkParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("dtype", "bsz", "n_heads", "q_len", "head_dim", "rows", "recent", "n_prune")] + \
+               [(n, ctypes.c_int64) for n in ("q_stride_b", "q_stride_h", "q_stride_l", "kc_stride_h")]
 
 
 class RaggedDecodeParams(ctypes.Structure):
@@ -99,6 +104,7 @@ def lib():
         L.kvc_merge_workspace_bytes.argtypes = [pp]
         L.kvc_merge_workspace_bytes.restype = sz
         L.kvc_merge_pivot.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+        L.kvc_think_prune.argtypes = [ctypes.POINTER(ThinkParams), vp, vp, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -430,6 +436,33 @@ def merge_pivot(method, k, v, idx, window, return_pivot=False, out=None):
     if return_pivot:
         m = int(dl.max())
         res.append(pivot.view(bsz, hq, L)[:, :, :m])
+    return tuple(res)
+
+
+def think_prune(kc, q, recent_size, ratio, return_scores=False):
+    """key_pruner_query_driven(kc, q, recent_size, ratio) (pyramidkv_utils.py:13-26) on the GPU (kvc_think_prune): kc [b, H, S, D]
+    the compressed keys (rows dense; a view with a head stride is fine), q [b, H, L, D].  Returns (kv_pruned
+    [b, H, S - recent, D - int(D * ratio)], kv_recent = kc[:, :, S - recent:], keep mask bool [b, H, D] (the reference's ~mask)
+    [, channel scores [b, H, D]])."""
+    _require_gpu(kc, q)
+    q = _last_dim_contig(q)
+    dev = _one_device(kc, q)
+    b, H, S, D = kc.shape
+    if kc.stride(3) != 1 or kc.stride(2) != D or kc.stride(0) != H * kc.stride(1):
+        kc = kc.contiguous()
+    n_prune = int(D * ratio)
+    p = ThinkParams()
+    p.dtype, p.bsz, p.n_heads, p.q_len, p.head_dim = DTYPES[kc.dtype], b, H, q.shape[2], D
+    p.rows, p.recent, p.n_prune = S, recent_size, n_prune
+    p.q_stride_b, p.q_stride_h, p.q_stride_l = q.stride(0), q.stride(1), q.stride(2)
+    p.kc_stride_h = kc.stride(1)
+    pruned = torch.empty(b, H, S - recent_size, D - n_prune, dtype=kc.dtype, device=dev)
+    keep = torch.empty(b, H, D, dtype=torch.uint8, device=dev)
+    sc = torch.empty(b, H, D, dtype=kc.dtype, device=dev) if return_scores else None
+    _check(_call(dev, lib().kvc_think_prune, ctypes.byref(p), _ptr(q), _ptr(kc), _ptr(pruned), _ptr(keep), _ptr(sc), _stream(dev)))
+    res = [pruned, kc[:, :, S - recent_size:, :], keep.bool()]
+    if return_scores:
+        res.append(sc)
     return tuple(res)
 
 

@@ -777,6 +777,28 @@ __attribute__((visibility("default"))) int kvc_merge_pivot(const kvc_params* p, 
     return hip_ok("merge launch");
 }
 
+// ---- ThinK channel pruning (pyramidkv_utils.py:13-26) -------------------------------------------------------
+__attribute__((visibility("default"))) int kvc_think_prune(const kvc_think_params* p, const void* q, const void* kc, void* pruned,
+                                                           uint8_t* keep, void* channel_scores, void* hip_stream) {
+    if (!p || !q || !kc || !keep) return fail(KVC_ERR_INVALID, "params, q, kc and keep must be non-NULL");
+    if (!pruned && p->rows > p->recent) return fail(KVC_ERR_INVALID, "pruned must be non-NULL");
+    if (p->dtype < KVC_BF16 || p->dtype > KVC_FP32) return fail(KVC_ERR_INVALID, "unknown dtype %d", p->dtype);
+    if (p->bsz < 1 || p->n_heads < 1) return fail(KVC_ERR_INVALID, "bsz / n_heads must be positive");
+    if (p->head_dim != 64 && p->head_dim != 128) return fail(KVC_ERR_UNSUPPORTED, "ThinK pruning is built for head_dim 64 and 128, got %d", p->head_dim);
+    if (p->q_len < 32) return fail(KVC_ERR_INVALID, "q_len %d < 32 (the reference reads the last 32 query rows, :17)", p->q_len);
+    if (p->rows < 1 || p->recent < 0 || p->recent > p->rows) return fail(KVC_ERR_INVALID, "recent=%d outside [0, rows=%d]", p->recent, p->rows);
+    if (p->n_prune < 0 || p->n_prune > p->head_dim) return fail(KVC_ERR_INVALID, "n_prune=%d outside [0, head_dim]", p->n_prune);
+    if (p->kc_stride_h < (int64_t)p->rows * p->head_dim) return fail(KVC_ERR_INVALID, "kc_stride_h smaller than rows * head_dim");
+    kvc::ThinkArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.q = q; a.kc = kc; a.pruned = pruned; a.keep = keep; a.scores = channel_scores;
+    a.q_stride_b = p->q_stride_b; a.q_stride_h = p->q_stride_h; a.q_stride_l = p->q_stride_l; a.kc_stride_h = p->kc_stride_h;
+    a.bsz = p->bsz; a.n_heads = p->n_heads; a.q_len = p->q_len; a.head_dim = p->head_dim;
+    a.rows = p->rows; a.recent = p->recent; a.n_prune = p->n_prune;
+    if (int rc = kvc::launch_think(a, p->dtype, static_cast<hipStream_t>(hip_stream))) return fail(rc, "think launch failed");
+    return hip_ok("think launch");
+}
+
 __attribute__((visibility("default"))) int kvc_ragged_decode_step(const kvc_ragged_decode_params* p, const void* q, const void* k_new,
                                                                   const void* v_new, void* k_flat, void* v_flat, const int64_t* seg_off,
                                                                   const int32_t* seg_len, void* out, void* hip_stream) {

@@ -97,6 +97,16 @@ struct MergeArgs {         // merge_kv pivot merge (kvc_merge.hip)
     int bsz, n_q_heads, group, q_len, window, n_keep, rows;      // rows = n_keep + window
 };
 
+struct ThinkArgs {         // ThinK channel pruning (kvc_think.hip)
+    const void* q;         // [bsz][n_heads][q_len][head_dim] by strides: the last 32 rows are read
+    const void* kc;        // compressed keys [bsz * n_heads][rows][head_dim], kc_stride_h elements between heads, rows dense
+    void* pruned;          // [bsz * n_heads][rows - recent][head_dim - n_prune]
+    uint8_t* keep;         // [bsz * n_heads][head_dim]: 1 = channel kept
+    void* scores;          // [bsz * n_heads][head_dim] dtype or null
+    int64_t q_stride_b, q_stride_h, q_stride_l, kc_stride_h;
+    int bsz, n_heads, q_len, head_dim, rows, recent, n_prune;
+};
+
 struct L2NormArgs {        // l2norm_kernel (L2NormCluster, pyramidkv_utils.py:419)
     const void* k;         // [bsz][n_kv_heads][q_len][head_dim] by strides (elements)
     void* norms;           // [bsz][n_q_heads][q_len] dtype: the norm of KV head h / group in every one of its query-head rows
@@ -169,6 +179,7 @@ int launch_decode_step(const DecodeArgs& a, int dtype, int head_dim, hipStream_t
 int launch_sort_prefix(const RaggedSortArgs& a, int dtype, void* scratch, hipStream_t st);
 int launch_l2norm(const L2NormArgs& a, int dtype, hipStream_t st);
 int launch_merge(const MergeArgs& a, int dtype, hipStream_t st);
+int launch_think(const ThinkArgs& a, int dtype, hipStream_t st);
 size_t sort_prefix_scratch_bytes(int heads, int n);
 int launch_ragged_plan(const RaggedArgs& a, int dtype, int bsz, hipStream_t st);
 int launch_ragged_head_stats(const RaggedArgs& a, int dtype, int bsz, hipStream_t st);

@@ -9,8 +9,8 @@ by one call into the HIP library (include/kvc.h: kvc_compress).  Differences, al
     H_q / H_kv — the outputs are identical ([bsz, H_q, cap, D]); the second form reads each KV head once.
   * the reference prints its budget on every call (pyramidkv_utils.py:217,312,539,601); here that is
     opt-in: set `kvcache_factory_amd.pyramidkv_utils.VERBOSE = True` (or KVC_VERBOSE=1).
-  * `merge="pivot"` (LOOK-M pivot merge, merge_kv :119-170) and L2NormCluster (:394-429) are built; CAM and
-    ThinK are not.
+  * `merge="pivot"` (LOOK-M pivot merge, merge_kv :119-170), L2NormCluster (:394-429) and SnapKVCluster.update_think (ThinK
+    channel pruning, :13-26, :349-392) are built; CAM and ThinK's model forward (llama_model_think.py) are not.
   * tensors must live on the GPU: there is no CPU / eager fallback.
   * `PrefillBatch` (not in the reference): the patched forwards hand every layer's (K, window-Q, V) to it and every
     GROUP_LAYERS-th layer (and the last) flushes the parked ones through ONE kvc_compress_batch call on a side stream,
@@ -209,7 +209,19 @@ class SnapKVCluster(_KVCluster):
     def __init__(self, window_size=64, max_capacity_prompt=256 + 64, kernel_size=5, pooling='avgpool', merge=None,
                  recent_size=32, ratio=0.4):
         super().__init__(window_size, max_capacity_prompt, kernel_size, pooling, merge)
-        self.recent_size, self.ratio = recent_size, ratio                  # ThinK knobs, unused on this path
+        self.recent_size, self.ratio = recent_size, ratio                  # ThinK knobs (update_think)
+
+    def update_think(self, key_states, query_states, value_states, attention_mask, num_key_value_groups):
+        """pyramidkv_utils.py:349-392: update_kv, then key_pruner_query_driven (:13-26) on the compressed keys.
+        Returns (kv_pruned [bsz, H, cap - recent_size, D - int(D * ratio)], kv_recent [bsz, H, recent_size, D], mask
+        [bsz, H, D] bool — True = channel kept —, value_states'); the pass-through and merge branches return what update_kv
+        returns (two tensors), like the reference (:360, :384)."""
+        bsz, num_heads, q_len, head_dim = self._prefill_shapes(key_states, query_states)
+        kc, vc = self.update_kv(key_states, query_states, value_states, attention_mask, num_key_value_groups)
+        if q_len < self.max_capacity_prompt or self.merge is not None:
+            return kc, vc
+        kv_pruned, kv_recent, mask = _kvc.think_prune(kc, query_states, self.recent_size, self.ratio)
+        return kv_pruned, kv_recent, mask, vc
 
 
 class PyramidKVCluster(_KVCluster):
@@ -388,6 +400,17 @@ def init_H2O(self):
 def init_StreamingLLM(self):
     """pyramidkv_utils.py:1011-1031 (default cap 2048)."""
     _init(self, StreamingLLMKVCluster, 2048)
+
+
+def init_think(self):
+    """pyramidkv_utils.py:926-952: SnapKV's defaults + recent_size 32, ratio 0.4; the caller uses kv_cluster.update_think."""
+    _init(self, SnapKVCluster, 4096, **{name: _default(self.config, name, val) for name, val in (("recent_size", 32), ("ratio", 0.4))})
+
+
+def _default(config, name, val):
+    if not hasattr(config, name):
+        setattr(config, name, val)
+    return getattr(config, name)
 
 
 def init_l2norm(self):

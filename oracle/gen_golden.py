@@ -142,6 +142,44 @@ def run_l2norm_case(c):
     return meta, out
 
 
+def run_think_case(c):
+    """SnapKVCluster.update_think (pyramidkv_utils.py:349-392): SnapKV compression, then key_pruner_query_driven (:13-26) on the
+    compressed keys.  Stored: the topk indices of the compression, the channel-keep mask, SHA-256 of kv_pruned / kv_recent / V',
+    and the channel scores the reference handed to its topk(largest=False) (second .topk call)."""
+    dtype = DT[c["dtype"]]
+    q, k, v = synth.make_qkv(c["Hq"], c["Hkv"], c["L"], c["D"], dtype, c["seed"], peaky=c.get("peaky", False), expanded=True)
+    cl = ref.SnapKVCluster(window_size=c["W"], max_capacity_prompt=c["cap"], kernel_size=c["kernel"], pooling=c["pooling"],
+                           recent_size=c["recent"], ratio=c["ratio"])
+    taps = []
+    orig = torch.topk
+
+    def ttopk(t, *a, **kwa):
+        r = orig(t, *a, **kwa)
+        taps.append((t.detach().clone(), r.indices.detach().clone()))
+        return r
+    torch.topk = ttopk
+    try:
+        t0 = time.time()
+        with TopkTap() as tap, contextlib.redirect_stdout(io.StringIO()):
+            res = cl.update_think(k, q, v, None, c["Hq"] // c["Hkv"])
+        dt = time.time() - t0
+    finally:
+        torch.topk = orig
+    meta = dict(c)
+    meta["ref_seconds"] = round(dt, 4)
+    meta["passthrough"] = len(res) == 2
+    out = {}
+    if len(res) == 4:
+        pruned, recent, keep, vo = res
+        meta["out_shape"] = list(pruned.shape)
+        meta["pruned_sha256"], meta["recent_sha256"], meta["v_out_sha256"] = sha(pruned), sha(recent), sha(vo)
+        meta["n_keep"] = int(tap.calls[0][2].shape[-1])
+        out["indices"] = tap.calls[0][2][0].numpy().astype(np.int64)
+        out["keep"] = keep[0].numpy().astype(np.uint8)
+        out["channel_scores"] = raw_bits(taps[-1][0][0])
+    return meta, out
+
+
 def run_merge_case(c):
     """SnapKV / PyramidKV / H2O with merge="pivot" (merge_kv, pyramidkv_utils.py:119-170, called at :337-339): stored are the topk
     indices the reference selected, the pivot (argmax) row of every dropped token (captured at its similarity.max call), the number
@@ -310,6 +348,13 @@ def cases():
     add("merge_h2o_bf16_L300", method="merge_h2o", dtype="bf16", Hq=4, Hkv=2, L=300, D=128, W=8, cap=48)
     add("merge_snapkv_bf16_peaky_L1024", method="merge_snapkv", dtype="bf16", Hq=8, Hkv=2, L=1024, D=128, W=8, cap=136, kernel=7, pooling="maxpool", peaky=True)
     add("merge_snapkv_8k_bf16", method="merge_snapkv", dtype="bf16", Hq=32, Hkv=8, L=8000, D=128, W=8, cap=128, kernel=7, pooling="maxpool", seed=0, store_out=True)
+    # ---- ThinK channel pruning behind SnapKV (update_think) ----
+    for dt in ("bf16", "fp16", "fp32"):
+        add(f"think_{dt}_L600", method="think", dtype=dt, Hq=8, Hkv=2, L=600, D=128, W=8, cap=72, kernel=7, pooling="maxpool", recent=32, ratio=0.4)
+        add(f"think_{dt}_D64_L300", method="think", dtype=dt, Hq=4, Hkv=4, L=300, D=64, W=16, cap=80, kernel=5, pooling="avgpool", recent=16, ratio=0.3)
+    add("think_bf16_passthrough", method="think", dtype="bf16", Hq=4, Hkv=2, L=60, D=64, W=8, cap=128, kernel=7, pooling="maxpool", recent=32, ratio=0.4)
+    add("think_8k_bf16", method="think", dtype="bf16", Hq=32, Hkv=8, L=8000, D=128, W=8, cap=128, kernel=7, pooling="maxpool", recent=32, ratio=0.4, seed=0)
+    add("think_8k_bf16_cap2048", method="think", dtype="bf16", Hq=32, Hkv=8, L=8000, D=128, W=32, cap=2048, kernel=7, pooling="maxpool", recent=128, ratio=0.3, seed=0)
     # ---- L2Norm (smallest key norms, ascending; no window, no query) ----
     for dt in ("bf16", "fp16", "fp32"):
         add(f"l2norm_{dt}_L600", method="l2norm", layer_idx=5, dtype=dt, Hq=8, Hkv=2, L=600, D=128, cap=96)
@@ -341,6 +386,8 @@ def main():
             meta, arrays = run_ragged_case(c)
         elif c["method"] == "l2norm":
             meta, arrays = run_l2norm_case(c)
+        elif c["method"] == "think":
+            meta, arrays = run_think_case(c)
         elif c["method"].startswith("merge_"):
             meta, arrays = run_merge_case(c)
         else:

@@ -720,6 +720,64 @@ KVCO_API int kvco_merge_pivot(const kvco_params* P, const void* k, const void* v
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// ThinK channel pruning, key_pruner_query_driven (pyramidkv_utils.py:13-26), called by SnapKVCluster.update_think
+// (:391) on the COMPRESSED keys [1, H, S, D] and the full queries:
+//   k = int(head_dim * ratio);  queries_norm = pow(q[..., -32:, :], 2).mean(dim=2);  keys_norm = pow(kv, 2).mean(dim=2)      (:15-18)
+//   key = queries_norm * keys_norm;  _, indices = topk(key, k, largest=False);  mask = scatter(indices) -> pruned channels      (:19-23)
+//   returns kv[:, :, :S - recent][~mask]  ->  [1, H, S - recent, D - k]   (channels in order), kv[:, :, S - recent:], ~mask       (:26)
+// Arithmetic: pow(x, 2) = x * x rounded to the dtype; mean(dim=2) = cast to fp32, torch's outer-dimension cascade sum over the
+// rows (CascadeSum above), / rows, ONE rounding (ReduceOps mean_out); the product rounded; topk largest=False = libstdc++
+// nth_element + sort (k * 64 > 128 always) with the comparator (!isnan(a) && isnan(b)) || a < b on (value, index).
+// ----------------------------------------------------------------------------------------
+template <class DT>
+static int think_impl(const kvco_params& P, const void* q_, const void* kc_, int64_t S, int64_t recent, int64_t n_prune,
+                      void* pruned_out, uint8_t* keep_out, void* score_out) {
+    typedef typename DT::raw raw;
+    const int H = P.n_q_heads, D = P.head_dim;
+    const int64_t L = P.q_len, QR = 32;
+    const raw* q = (const raw*)q_; const raw* kc = (const raw*)kc_;
+    for (int h = 0; h < H; ++h) {
+        std::vector<float> sc((size_t)D);
+        for (int d = 0; d < D; ++d) {
+            CascadeSum a; a.init(QR);
+            for (int64_t r = 0; r < QR; ++r) { const float x = DT::ld(q[(int64_t)h * P.q_stride_h + (L - QR + r) * P.q_stride_l + d]); a.add(rnd<DT>(x * x)); }
+            CascadeSum b; b.init(S);
+            for (int64_t r = 0; r < S; ++r) { const float x = DT::ld(kc[((int64_t)h * S + r) * D + d]); b.add(rnd<DT>(x * x)); }
+            sc[(size_t)d] = rnd<DT>(rnd<DT>(a.result() / (float)QR) * rnd<DT>(b.result() / (float)S));
+            if (score_out) ((raw*)score_out)[(int64_t)h * D + d] = DT::st(sc[(size_t)d]);
+        }
+        typedef std::pair<float, int64_t> elem;
+        std::vector<elem> e((size_t)D);
+        for (int d = 0; d < D; ++d) e[(size_t)d] = elem(sc[(size_t)d], d);
+        auto comp = [](const elem& x, const elem& y) -> bool { return ((!std::isnan(x.first) && std::isnan(y.first)) || (x.first < y.first)); };
+        if (n_prune > 0) {
+            if (n_prune * 64 <= D) std::partial_sort(e.begin(), e.begin() + n_prune, e.end(), comp);
+            else { std::nth_element(e.begin(), e.begin() + (n_prune - 1), e.end(), comp); std::sort(e.begin(), e.begin() + (n_prune - 1), comp); }
+        }
+        std::vector<uint8_t> keep((size_t)D, 1);
+        for (int64_t t = 0; t < n_prune; ++t) keep[(size_t)e[(size_t)t].second] = 0;
+        for (int d = 0; d < D; ++d) keep_out[(int64_t)h * D + d] = keep[(size_t)d];
+        raw* o = (raw*)pruned_out + (int64_t)h * (S - recent) * (D - n_prune);
+        for (int64_t r = 0; r < S - recent; ++r)
+            for (int d = 0; d < D; ++d)
+                if (keep[(size_t)d]) *o++ = kc[((int64_t)h * S + r) * D + d];
+    }
+    return 0;
+}
+// q: [H][L][D] by P's q strides (the last 32 rows are read); kc: the compressed keys, dense [H][S][D].
+// pruned_out [H][S - recent][D - n_prune]; keep_out [H][D] (1 = channel kept = the reference's returned ~mask); score_out [H][D] or null.
+KVCO_API int kvco_think_prune(const kvco_params* P, const void* q, const void* kc, int64_t S, int64_t recent, int64_t n_prune,
+                              void* pruned_out, uint8_t* keep_out, void* score_out) {
+    if (P->dtype < 0 || P->dtype > 2 || P->n_q_heads <= 0 || P->head_dim <= 0 || P->q_len < 32) return -1;
+    if (S <= 0 || recent < 0 || recent > S || n_prune < 0 || n_prune > P->head_dim) return -1;
+    switch (P->dtype) {
+        case KVCO_BF16: return think_impl<DtBf16>(*P, q, kc, S, recent, n_prune, pruned_out, keep_out, score_out);
+        case KVCO_FP16: return think_impl<DtFp16>(*P, q, kc, S, recent, n_prune, pruned_out, keep_out, score_out);
+        default:        return think_impl<DtFp32>(*P, q, kc, S, recent, n_prune, pruned_out, keep_out, score_out);
+    }
+}
+
 // Scalar probes used by tests to pin the helper arithmetic.
 KVCO_API float kvco_exp_u20(float x) { return exp_u20(x); }
 KVCO_API float kvco_sum(const float* x, int64_t n, int sum_mode) {

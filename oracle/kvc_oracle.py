@@ -61,6 +61,7 @@ def lib():
         L.kvco_ragged_gather.argtypes = [pp, vp, ctypes.c_int64, ctypes.c_int64, i64p, vp, vp]
         L.kvco_l2norm.argtypes = [pp, vp, vp, vp, i64p, vp, vp]
         L.kvco_merge_pivot.argtypes = [pp, vp, vp, i64p, vp, vp, vp, vp]
+        L.kvco_think_prune.argtypes = [pp, vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, vp]
         L.kvco_pyramid_k.argtypes = [ctypes.c_int64] * 6
         L.kvco_pyramid_k.restype = ctypes.c_int64
         L.kvco_exp_u20.argtypes = [ctypes.c_float]
@@ -230,6 +231,26 @@ def merge_pivot(k, v, idx, window, n_threads=0):
     _rc(lib().kvco_merge_pivot(ctypes.byref(p), _ptr(k), _ptr(v), _ptr(idx), _ptr(ko), _ptr(vo), _ptr(pivot), ctypes.byref(dl)), "merge_pivot")
     M = int(dl.value)
     return ko, vo, pivot.view(-1)[: H * M].view(H, M).clone()
+
+
+def think_prune(kc, q, recent_size, ratio):
+    """key_pruner_query_driven(kc, q, recent_size, ratio) (pyramidkv_utils.py:13-26): kc [1, H, S, D] compressed keys, q [1, H, L, D].
+    Returns (kv_pruned [1, H, S - recent, D - k], kv_recent [1, H, recent, D], keep mask bool [1, H, D] (= the reference's ~mask),
+    channel scores [H, D])."""
+    _check_inner(q)
+    kc = kc.contiguous()
+    H, S, D = kc.shape[1], kc.shape[2], kc.shape[3]
+    n_prune = int(D * ratio)
+    p = Params()
+    p.dtype = _DTYPE[kc.dtype]
+    p.n_q_heads = p.n_kv_heads = H
+    p.q_len, p.head_dim = q.shape[2], D
+    p.q_stride_h, p.q_stride_l = q.stride(1), q.stride(2)
+    pruned = torch.empty(1, H, S - recent_size, D - n_prune, dtype=kc.dtype)
+    keep = torch.empty(1, H, D, dtype=torch.uint8)
+    sc = torch.empty(H, D, dtype=kc.dtype)
+    _rc(lib().kvco_think_prune(ctypes.byref(p), _ptr(q), _ptr(kc), S, recent_size, n_prune, _ptr(pruned), _ptr(keep), _ptr(sc)), "think_prune")
+    return pruned, kc[:, :, S - recent_size:, :], keep.bool(), sc
 
 
 def l2norm(k, v, max_capacity_prompt, n_q_heads, n_threads=0):

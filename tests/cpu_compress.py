@@ -74,3 +74,9 @@ def oracle_compress_merge(method, q, k, v, window, n_keep, kernel_size=5, poolin
         idx, _ = O.topk(sc, n_keep, O.TIES_TORCH if tie_mode in ("torch_cpu", 0) else O.TIES_CANON)
     ko, vo, _ = O.merge_pivot(k, v, idx, window)
     return ko, vo
+
+
+def oracle_think_prune(kc, q, recent_size, ratio, return_scores=False):
+    """Stand-in for _kvc.think_prune (host-logic tests only)."""
+    pruned, recent, keep, sc = O.think_prune(kc, q.contiguous(), recent_size, ratio)
+    return (pruned, recent, keep, sc[None]) if return_scores else (pruned, recent, keep)

@@ -1154,3 +1154,48 @@ def test_streamingllm_with_pivot_merge_on_gpu(kvc, oracle, gpu_device):
     idx = torch.arange(64, dtype=torch.int64).expand(8, 64).contiguous()
     ko_o, vo_o, _ = oracle.merge_pivot(k, v, idx, 16)
     assert torch.equal(G.bits(ko.cpu()), G.bits(ko_o)) and torch.equal(G.bits(vo.cpu()), G.bits(vo_o))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", G.names(lambda m: m["method"] == "think" and not m["passthrough"]))
+def test_think_prune_vs_reference(kvc, gpu_device, name):
+    """SURVEY 8f N4, ThinK: SnapKVCluster.update_think on the GPU — compression (scoring, exact-tie top-k, gather) and
+    kvc_think_prune (channel scores in torch's arithmetic, torch-CPU topk(largest=False) tie order, channel compaction) —
+    returns the reference's pruned keys, recent keys, channel mask and values (SHA-256); the channel scores are compared bit
+    for bit with what the reference handed to its topk.  fp32: compared where the compression picked the reference's indices."""
+    from kvcache_factory_amd import pyramidkv_utils as pu
+    m = G.MANIFEST[name]
+    a = G.arrays(name)
+    q, k, v = G.inputs(m)
+    g = m["Hq"] // m["Hkv"]
+    cl = pu.SnapKVCluster(window_size=m["W"], max_capacity_prompt=m["cap"], kernel_size=m["kernel"], pooling=m["pooling"],
+                          recent_size=m["recent"], ratio=m["ratio"])
+    qd, kd, vd = q.to(gpu_device), k[:, ::g].contiguous().to(gpu_device), v[:, ::g].contiguous().to(gpu_device)
+    kc, vc, idx = kvc.compress(kvc.SNAPKV, qd, kd, vd, m["W"], m["n_keep"], m["kernel"], m["pooling"], "torch_cpu", return_indices=True)
+    same_idx = torch.equal(idx[0].cpu(), torch.from_numpy(a["indices"]))
+    assert same_idx or m["dtype"] == "fp32"
+    pruned, recent, mask, sc = kvc.think_prune(kc, qd, m["recent"], m["ratio"], return_scores=True)
+    if same_idx:
+        assert torch.equal(G.bits(sc[0].cpu()), torch.from_numpy(a["channel_scores"]))
+        assert torch.equal(mask[0].cpu(), torch.from_numpy(a["keep"]).bool())
+        assert G.sha(pruned.cpu()) == m["pruned_sha256"] and G.sha(recent.cpu().contiguous()) == m["recent_sha256"]
+        p2, r2, m2, v2 = cl.update_think(kd, qd, vd, None, g)
+        assert torch.equal(G.bits(p2.cpu()), G.bits(pruned.cpu())) and torch.equal(m2, mask) and G.sha(v2.cpu().contiguous()) == m["v_out_sha256"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("S,D,recent,ratio", [(40, 64, 0, 0.5), (128, 128, 32, 0.4), (300, 128, 300, 0.3), (2056, 128, 128, 0.01), (77, 64, 5, 0.99)])
+def test_think_prune_corners_vs_oracle(kvc, oracle, gpu_device, S, D, recent, ratio, dtype):
+    """kvc_think_prune against the oracle on coarse inputs (many equal channel scores: the smallest-k tie order matters), with no
+    recent rows, only recent rows, one and nearly all channels pruned, and a compressed-key view with spare rows per head."""
+    g = torch.Generator().manual_seed(S * 7 + D)
+    q = (torch.randn(1, 4, 200, D, generator=g) * 2).round().div(2).to(dtype)
+    kbuf = torch.zeros(1, 4, S + 9, D, dtype=dtype)
+    kbuf[:, :, :S] = (torch.randn(1, 4, S, D, generator=g) * 2).round().div(2).to(dtype)
+    pruned_o, recent_o, keep_o, sc_o = oracle.think_prune(kbuf[:, :, :S].contiguous(), q, recent, ratio)
+    kd = kbuf.to(gpu_device)
+    pruned, rec, keep, sc = kvc.think_prune(kd[:, :, :S], q.to(gpu_device), recent, ratio, return_scores=True)
+    assert torch.equal(G.bits(sc[0].cpu()), G.bits(sc_o))
+    assert torch.equal(keep.cpu(), keep_o)
+    assert torch.equal(G.bits(pruned.cpu()), G.bits(pruned_o)) and torch.equal(G.bits(rec.cpu().contiguous()), G.bits(recent_o.contiguous()))

@@ -211,3 +211,18 @@ def test_merge_pivot_against_reference(oracle, name):
     assert piv.shape[1] == m["drop_len"]
     assert torch.equal(piv, torch.from_numpy(a["pivot"].astype("int32")))
     assert G.sha(ko) == m["k_out_sha256"] and G.sha(vo) == m["v_out_sha256"]
+
+
+@pytest.mark.parametrize("name", G.names(lambda m: m["method"] == "think" and not m["passthrough"]))
+def test_think_prune_against_reference(oracle, name):
+    """SURVEY 8f N4, key_pruner_query_driven (pyramidkv_utils.py:13-26) on the keys compressed with the reference's own topk indices:
+    channel scores bit for bit (captured at the reference's topk(largest=False)), the channel mask, and the pruned / recent keys
+    (SHA-256) — every dtype, 8k -> 128 and 8k -> 2048 included."""
+    m = G.MANIFEST[name]
+    a = G.arrays(name)
+    q, k, v = G.inputs(m)
+    kc = oracle.gather(k, torch.from_numpy(a["indices"]).contiguous(), m["W"], m["Hq"])
+    pruned, recent, keep, sc = oracle.think_prune(kc, q, m["recent"], m["ratio"])
+    assert torch.equal(G.bits(sc), torch.from_numpy(a["channel_scores"]))
+    assert torch.equal(keep[0], torch.from_numpy(a["keep"]).bool())
+    assert G.sha(pruned) == m["pruned_sha256"] and G.sha(recent.contiguous()) == m["recent_sha256"]

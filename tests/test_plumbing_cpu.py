@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import golden_util as G
-from cpu_compress import oracle_compress, oracle_compress_batch, oracle_compress_merge, oracle_l2norm_compress
+from cpu_compress import oracle_compress, oracle_compress_batch, oracle_compress_merge, oracle_l2norm_compress, oracle_think_prune
 from kvcache_factory_amd import _kvc, monkeypatch as mp, pyramidkv_utils as pu
 
 
@@ -18,6 +18,7 @@ def cpu_backend(monkeypatch, oracle):
     monkeypatch.setattr(_kvc, "compress_batch", oracle_compress_batch)
     monkeypatch.setattr(_kvc, "l2norm_compress", oracle_l2norm_compress)
     monkeypatch.setattr(_kvc, "compress_merge", oracle_compress_merge)
+    monkeypatch.setattr(_kvc, "think_prune", oracle_think_prune)
     monkeypatch.setattr(pu, "BATCH_LAYERS", False)       # these tests watch one update_kv per layer
     yield
 
@@ -469,3 +470,32 @@ def test_cluster_with_pivot_merge_matches_reference_fixture(cpu_backend, name):
         ko, vo = cls(**kw).update_kv(kk, q, vv, None, g)
         assert list(ko.shape) == m["out_shape"]
         assert G.sha(ko) == m["k_out_sha256"] and G.sha(vo) == m["v_out_sha256"]
+
+
+@pytest.mark.parametrize("name", ["think_bf16_L600", "think_fp16_D64_L300", "think_fp32_L600"])
+def test_update_think_matches_reference_fixture(cpu_backend, name):
+    """SnapKVCluster.update_think (pyramidkv_utils.py:349-392): the four return values of the reference — pruned keys, recent keys,
+    channel mask, compressed values — and the two-tensor pass-through; init_think's defaults (:926-952)."""
+    m = G.MANIFEST[name]
+    a = G.arrays(name)
+    q, k, v = G.inputs(m)
+    g = m["Hq"] // m["Hkv"]
+    cl = pu.SnapKVCluster(window_size=m["W"], max_capacity_prompt=m["cap"], kernel_size=m["kernel"], pooling=m["pooling"],
+                          recent_size=m["recent"], ratio=m["ratio"])
+    pruned, recent, mask, vo = cl.update_think(k[:, ::g].contiguous(), q, v[:, ::g].contiguous(), None, g)
+    assert list(pruned.shape) == m["out_shape"] and mask.dtype == torch.bool
+    assert G.sha(pruned) == m["pruned_sha256"] and G.sha(recent.contiguous()) == m["recent_sha256"] and G.sha(vo) == m["v_out_sha256"]
+    assert torch.equal(mask[0], torch.from_numpy(a["keep"]).bool())
+    short = pu.SnapKVCluster(window_size=8, max_capacity_prompt=4096).update_think(k, q, v, None, g)
+    assert len(short) == 2 and short[0] is k and short[1] is v
+
+    class Cfg:
+        pass
+
+    class Attn:
+        def __init__(self):
+            self.config, self.layer_idx = Cfg(), 0
+    at = Attn()
+    pu.init_think(at)
+    assert (at.config.recent_size, at.config.ratio, at.config.max_capacity_prompt) == (32, 0.4, 4096)
+    assert isinstance(at.kv_cluster, pu.SnapKVCluster) and at.kv_cluster.recent_size == 32
