@@ -525,6 +525,30 @@ def main():
                 pu.TIE_MODE = old
             except Exception as e:
                 extra["host_path_error"] = repr(e)
+            try:        # SURVEY 8f N4 on one layer of this configuration (HIP events around 20 calls each; us per layer call)
+                q0, k0, v0 = inputs[0][0]
+                W0, keep0 = cfg["W"], ks[0]
+
+                def per_call_us(fn, reps=20):
+                    for _ in range(3):
+                        fn()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(reps):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize(dev)
+                    return e0.elapsed_time(e1) * 1e3 / reps
+                sc0 = _kvc.scores(METHODS[cfg["method"]], q0, k0, W0, cfg["kernel"], cfg["pooling"])
+                idx0 = _kvc.select(sc0, keep0, a.tie_mode)
+                kc0 = _kvc.compress(METHODS[cfg["method"]], q0, k0, v0, W0, keep0, cfg["kernel"], cfg["pooling"], a.tie_mode)[0]
+                extra["n4_us_per_layer_call"] = {
+                    "l2norm_compress_rows_%d" % cfg["cap"]: per_call_us(lambda: _kvc.l2norm_compress(k0, v0, cfg["cap"], n_q_heads=HQ)),
+                    "merge_pivot_after_scores_and_select": per_call_us(lambda: _kvc.merge_pivot(METHODS[cfg["method"]], k0, v0, idx0, W0)),
+                    "think_prune_recent32_ratio0.4": per_call_us(lambda: _kvc.think_prune(kc0, q0, min(32, kc0.shape[2]), 0.4)),
+                    "note": "Python binding included (output allocation, ctypes call); kernel times in profiles/r02_kernel_stats_n4_*.csv"}
+            except Exception as e:
+                extra["n4_error"] = repr(e)
             out["extras"] = extra
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, dev=dev)

@@ -499,3 +499,19 @@ def test_update_think_matches_reference_fixture(cpu_backend, name):
     pu.init_think(at)
     assert (at.config.recent_size, at.config.ratio, at.config.max_capacity_prompt) == (32, 0.4, 4096)
     assert isinstance(at.kv_cluster, pu.SnapKVCluster) and at.kv_cluster.recent_size == 32
+
+
+def test_pivot_merge_through_the_model(cpu_backend):
+    """replace_llama("snapkv") with config.merge = "pivot" (run_longbench.py writes the knob onto every layer's config): prefill
+    takes the direct path (merge_kv is not batched), the cache holds cap rows per layer, decode appends and generation runs."""
+    ids = torch.randint(0, 512, (1, 96))
+    mp.replace_llama("snapkv")
+    try:
+        model = _llama(layers=2, dtype=torch.bfloat16)                         # merge_kv is built for the 16-bit dtypes
+        _set_knobs(model, window_size=8, max_capacity_prompt=40, kernel_size=7, pooling="maxpool", merge="pivot")
+        out = _generate(model, ids, 3)
+        cache = out.past_key_values
+        assert [cache.layers[i].keys.shape[2] for i in range(2)] == [40 + 2, 40 + 2]
+        assert cache.get_seq_length() == 96 + 2
+    finally:
+        mp.replace_llama("fullkv")
