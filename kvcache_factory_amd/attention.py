@@ -25,7 +25,7 @@ import torch
 from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
 
 from . import pyramidkv_utils as pu
-from .cache import CompressedDynamicLayer, RaggedDynamicLayer
+from .cache import CompressedDynamicLayer, RaggedDynamicLayer, ThinkDynamicLayer
 
 _INIT = {
     "pyramidkv": lambda self: pu.init_pyramidkv(self, num_hidden_layers=self.config.num_hidden_layers),
@@ -198,4 +198,55 @@ def make_ragged_forward(method, apply_rotary_pos_emb, eager_attention_forward, r
 
     forward.__name__ = f"kvc_attn_forward_{method}"
     forward.kvc_method = method
+    return forward
+
+
+def make_think_forward(apply_rotary_pos_emb, eager_attention_forward, repeat_kv):
+    """ThinK forward — counterpart of llama_attn_forward_SnapKV_ThinK (llama_model_think.py:86-218): prefill compresses with
+    SnapKV and prunes key channels (kv_cluster.update_think, on the GPU through kvc_compress + kvc_think_prune) into a
+    ThinkDynamicLayer; this step's attention runs over the uncompressed K/V; a decode step attends over [channel-pruned rows |
+    recent + decoded rows] with torch ops, as the reference does (:175-196)."""
+
+    def forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None, **kwargs):
+        pu.init_think(self)
+        input_shape = hidden_states.shape[:-1]
+        hidden_shape = (*input_shape, -1, self.head_dim)
+        query_states = self.q_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+        key_states = self.k_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+        value_states = self.v_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+        cos, sin = position_embeddings
+        query_states, key_states = apply_rotary_pos_emb(query_states, key_states, cos, sin)
+        if past_key_values is not None:
+            layers = past_key_values.layers
+            while len(layers) <= self.layer_idx:
+                layers.append(ThinkDynamicLayer())
+            layer = layers[self.layer_idx]
+            if not isinstance(layer, ThinkDynamicLayer):
+                if layer.get_seq_length() != 0:
+                    raise RuntimeError("kvcache_factory_amd: the cache already holds uncompressed tokens for this layer")
+                layer = layers[self.layer_idx] = ThinkDynamicLayer()
+            if layer.get_seq_length() == 0:                                  # prefill
+                q_len = key_states.shape[-2]
+                res = self.kv_cluster.update_think(key_states, query_states, value_states, attention_mask, self.num_key_value_groups)
+                if len(res) == 2:
+                    kc, vc = res
+                    if kc is key_states:
+                        kc, vc = repeat_kv(key_states, self.num_key_value_groups), repeat_kv(value_states, self.num_key_value_groups)
+                    layer.prefill_plain(kc, vc, q_len)
+                else:
+                    layer.prefill_think(*res, q_len)
+            else:                                                            # decode
+                out = layer.attend(query_states, repeat_kv(key_states, self.num_key_value_groups),
+                                   repeat_kv(value_states, self.num_key_value_groups), self.scaling)
+                return self.o_proj(out.reshape(*input_shape, -1)), None
+        attention_interface: Callable = ALL_ATTENTION_FUNCTIONS.get_interface(
+            self.config._attn_implementation, eager_attention_forward)
+        attn_output, attn_weights = attention_interface(
+            self, query_states, key_states, value_states, attention_mask,
+            dropout=0.0 if not self.training else self.attention_dropout, scaling=self.scaling, **kwargs)
+        attn_output = attn_output.reshape(*input_shape, -1).contiguous()
+        return self.o_proj(attn_output), attn_weights
+
+    forward.__name__ = "kvc_attn_forward_think"
+    forward.kvc_method = "think"
     return forward

@@ -222,3 +222,81 @@ class RaggedDynamicLayer(DynamicLayer):
 
     def crop(self, *a, **kw):
         raise NotImplementedError("a compressed cache cannot be cropped by position")
+
+
+class ThinkDynamicLayer(DynamicLayer):
+    """ThinK's cache for one layer — counterpart of the reference's cache_utils_think.DynamicCache (key_cache_pruned, mask,
+    key_cache, value_cache; `update_think`, llama_model_think.py:167-168): the compressed keys are stored WITHOUT their pruned
+    channels except the last `recent_size` rows; decoded tokens join the full-channel rows.  A decode step attends over
+    [pruned rows | recent + decoded rows] with the query's kept channels for the first part (llama_model_think.py:175-182).
+    Rows are appended in place into buffers with spare rows."""
+    RESERVE = 256
+
+    def __init__(self):
+        super().__init__()
+        self.true_length = 0
+        self.key_pruned = None          # [bsz, H, cap - recent, D - k] or None (pass-through prompt: nothing pruned)
+        self.mask = None                # [bsz, H, D] bool, True = channel kept
+        self._kbuf = self._vbuf = None  # [bsz, H, capacity, D]: recent + decoded keys / all values
+        self._kn = self._vn = 0
+
+    keys = property(lambda self: None if self._kbuf is None else self._kbuf[:, :, :self._kn], lambda self, v: None)
+    values = property(lambda self: None if self._vbuf is None else self._vbuf[:, :, :self._vn], lambda self, v: None)
+
+    def _store(self, k_full, v_all):
+        b, h, _, d = v_all.shape
+        self._kbuf = torch.empty(b, h, k_full.shape[2] + self.RESERVE, d, dtype=v_all.dtype, device=v_all.device)
+        self._vbuf = torch.empty(b, h, v_all.shape[2] + self.RESERVE, d, dtype=v_all.dtype, device=v_all.device)
+        self._kn, self._vn = k_full.shape[2], v_all.shape[2]
+        self._kbuf[:, :, :self._kn].copy_(k_full)
+        self._vbuf[:, :, :self._vn].copy_(v_all)
+
+    def prefill_think(self, kv_pruned, kv_recent, mask, values, true_length):
+        if not self.is_initialized:
+            self.lazy_initialization(kv_recent, values)
+        self.key_pruned, self.mask = kv_pruned, mask
+        self._store(kv_recent, values)
+        self.true_length = int(true_length)
+
+    def prefill_plain(self, keys, values, true_length):
+        """A prompt shorter than the budget (or a merged one): update_think returned plain (keys, values)."""
+        if not self.is_initialized:
+            self.lazy_initialization(keys, values)
+        self.key_pruned, self.mask = None, None
+        self._store(keys, values)
+        self.true_length = int(true_length)
+
+    def attend(self, query_states, k_new, v_new, scaling):
+        """Append the step's H-head rows and return the attention output [bsz, t, H, D] (llama_model_think.py:170-196)."""
+        t = k_new.shape[2]
+        if self._kn + t > self._kbuf.shape[2] or self._vn + t > self._vbuf.shape[2]:
+            self._store(self.keys, self.values)                           # fresh buffers with RESERVE spare rows again
+        self._kbuf[:, :, self._kn:self._kn + t].copy_(k_new)
+        self._vbuf[:, :, self._vn:self._vn + t].copy_(v_new)
+        self._kn += t
+        self._vn += t
+        self.true_length += t
+        logits = torch.matmul(query_states, self.keys.transpose(2, 3))
+        if self.key_pruned is not None:
+            b, h, _, d = query_states.shape
+            qm = query_states[self.mask.unsqueeze(2).expand(-1, -1, t, -1)].view(b, h, t, -1)
+            logits = torch.cat([torch.matmul(qm, self.key_pruned.transpose(2, 3)), logits], dim=-1)
+        logits = logits * scaling
+        if t > 1:                                                          # the step's own tokens are causal among themselves
+            n = logits.shape[-1]
+            causal = torch.full((t, t), torch.finfo(logits.dtype).min, device=logits.device, dtype=logits.dtype).triu(1)
+            logits[..., n - t:] = logits[..., n - t:] + causal
+        w = torch.nn.functional.softmax(logits, dim=-1, dtype=torch.float32).to(query_states.dtype)
+        return torch.matmul(w, self.values).transpose(1, 2)
+
+    def stored_length(self):
+        return self._vn
+
+    def get_seq_length(self):
+        return self.true_length
+
+    def get_mask_sizes(self, query_length):
+        return self._vn + query_length, 0
+
+    def crop(self, *a, **kw):
+        raise NotImplementedError("a compressed cache cannot be cropped by position")

@@ -3,7 +3,7 @@ sdpa :208/:1305/:1663/:2020 and flash-attn copies of one template).  transformer
 whose backend is picked at call time, so one forward per method replaces the reference's three."""
 from transformers.models.llama import modeling_llama as _ml
 
-from .attention import make_forward, make_ragged_forward
+from .attention import make_forward, make_ragged_forward, make_think_forward
 
 
 def _mk(method):
@@ -18,7 +18,9 @@ llama_attn_forward_L2Norm = llama_sdpa_attn_forward_L2Norm = _mk("l2norm")      
 # AdaKV / HeadKV: the reference only has flash-attn forwards for them (llama_model.py:2255, :2400)
 llama_flash_attn2_forward_AdaKV = make_ragged_forward("adakv", _ml.apply_rotary_pos_emb, _ml.eager_attention_forward, _ml.repeat_kv)
 llama_flash_attn2_forward_HeadKV = make_ragged_forward("headkv", _ml.apply_rotary_pos_emb, _ml.eager_attention_forward, _ml.repeat_kv)
+# ThinK: llama_model_think.py:86 (the reference patches Llama only, monkeypatch.py:80-83)
+llama_attn_forward_SnapKV_ThinK = make_think_forward(_ml.apply_rotary_pos_emb, _ml.eager_attention_forward, _ml.repeat_kv)
 FORWARDS = {"pyramidkv": llama_attn_forward_PyramidKV, "snapkv": llama_attn_forward_SnapKV,
             "h2o": llama_attn_forward_H2O, "streamingllm": llama_attn_forward_StreamingLLM,
             "adakv": llama_flash_attn2_forward_AdaKV, "headkv": llama_flash_attn2_forward_HeadKV,
-            "l2norm": llama_attn_forward_L2Norm}
+            "l2norm": llama_attn_forward_L2Norm, "think": llama_attn_forward_SnapKV_ThinK}

@@ -2,15 +2,16 @@
 
 Call once BEFORE building the model, exactly like the reference (run_longbench.py:382-384); the per-layer knobs are
 then written onto `model.model.layers[i].self_attn.config.*` (run_longbench.py:253-261) and read by init_*.
-Methods in scope: "pyramidkv", "snapkv", "h2o", "streamingllm", "adakv", "headkv" and (N4) "l2norm"; "fullkv"
-leaves the model untouched (:86).  The reference's other method strings (cam, think, minference) are out of scope and raise.
+Methods in scope: "pyramidkv", "snapkv", "h2o", "streamingllm", "adakv", "headkv", (N4) "l2norm" and "think"
+(Llama only, like the reference, :80-83); "fullkv" leaves the model untouched (:86).  The reference's other method strings
+(cam, minference) are out of scope and raise.
 The reference also rebinds `prepare_inputs_for_generation` to reset `kv_seq_len` (llama_model.py:2598-2612); with
 transformers 5.x that bookkeeping lives in the cache layer (cache.CompressedDynamicLayer), so nothing else is patched.
 """
 import transformers
 
-_IN_SCOPE = ("pyramidkv", "snapkv", "h2o", "streamingllm", "adakv", "headkv", "l2norm")
-_OUT_OF_SCOPE = ("cam", "think", "minference")
+_IN_SCOPE = ("pyramidkv", "snapkv", "h2o", "streamingllm", "adakv", "headkv", "l2norm", "think")
+_OUT_OF_SCOPE = ("cam", "minference")
 _ORIGINALS = {}
 
 
@@ -23,6 +24,8 @@ def _patch(cls, forwards, method):
         raise NotImplementedError(f"method {method!r} is outside this build's scope (SURVEY.md §2 rows 5-11)")
     if method not in _IN_SCOPE:
         return                       # reference: unknown strings silently patch nothing (monkeypatch.py:19-87)
+    if method not in forwards:
+        raise NotImplementedError(f"the reference has no {method!r} forward for {cls.__name__} (monkeypatch.py:80-83)")
     _ORIGINALS.setdefault(cls, cls.forward)
     cls.forward = forwards[method]
 

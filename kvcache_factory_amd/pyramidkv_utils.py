@@ -10,7 +10,7 @@ by one call into the HIP library (include/kvc.h: kvc_compress).  Differences, al
   * the reference prints its budget on every call (pyramidkv_utils.py:217,312,539,601); here that is
     opt-in: set `kvcache_factory_amd.pyramidkv_utils.VERBOSE = True` (or KVC_VERBOSE=1).
   * `merge="pivot"` (LOOK-M pivot merge, merge_kv :119-170), L2NormCluster (:394-429) and SnapKVCluster.update_think (ThinK
-    channel pruning, :13-26, :349-392) are built; CAM and ThinK's model forward (llama_model_think.py) are not.
+    channel pruning, :13-26, :349-392; model forward in attention.make_think_forward) are built; CAM is not.
   * tensors must live on the GPU: there is no CPU / eager fallback.
   * `PrefillBatch` (not in the reference): the patched forwards hand every layer's (K, window-Q, V) to it and every
     GROUP_LAYERS-th layer (and the last) flushes the parked ones through ONE kvc_compress_batch call on a side stream,

@@ -1199,3 +1199,43 @@ def test_think_prune_corners_vs_oracle(kvc, oracle, gpu_device, S, D, recent, ra
     assert torch.equal(G.bits(sc[0].cpu()), G.bits(sc_o))
     assert torch.equal(keep.cpu(), keep_o)
     assert torch.equal(G.bits(pruned.cpu()), G.bits(pruned_o)) and torch.equal(G.bits(rec.cpu().contiguous()), G.bits(recent_o.contiguous()))
+
+
+@pytest.mark.gpu
+def test_think_patched_model_on_gpu(kvc, gpu_device, monkeypatch):
+    """replace_llama("think") on a small bf16 Llama ON THE GPU: prefill through kvc_compress + kvc_think_prune into a
+    ThinkDynamicLayer, decode over [channel-pruned rows | recent + decoded rows].  With ratio = 0 (nothing pruned) the logits of
+    the decode steps match plain SnapKV's run through the reference-shaped decode path (same cache contents; different attention
+    kernels: tolerance 3e-2 on bf16 logits of magnitude ~1); with ratio = 0.4 the cache has the reference's shapes."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from kvcache_factory_amd import monkeypatch as mp, pyramidkv_utils as pu
+    from kvcache_factory_amd.cache import ThinkDynamicLayer
+    monkeypatch.setattr(pu, "DECODE_KERNEL", False)
+    cfg = LlamaConfig(hidden_size=4096, intermediate_size=256, num_hidden_layers=2, num_attention_heads=32,
+                      num_key_value_heads=8, head_dim=128, vocab_size=256, max_position_embeddings=4096, attn_implementation="sdpa")
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(cfg).to(torch.bfloat16).to(gpu_device).eval()
+    ids = torch.randint(0, 256, (1, 400), generator=torch.Generator().manual_seed(5)).to(gpu_device)
+    knobs = dict(window_size=8, max_capacity_prompt=80, kernel_size=7, pooling="maxpool")
+    logits = {}
+    try:
+        for method, extra in (("snapkv", {}), ("think", dict(recent_size=16, ratio=0.0)), ("think", dict(recent_size=16, ratio=0.4))):
+            mp.replace_llama("fullkv"); mp.replace_llama(method)
+            for layer in model.model.layers:
+                for name, val in {**knobs, **extra}.items():
+                    setattr(layer.self_attn.config, name, val)
+                if hasattr(layer.self_attn, "kv_cluster"):
+                    del layer.self_attn.kv_cluster
+            with torch.no_grad():
+                out = model.generate(ids, max_new_tokens=4, do_sample=False, use_cache=True, return_dict_in_generate=True, output_logits=True)
+            logits[(method, extra.get("ratio"))] = torch.stack(out.logits).float().cpu()
+            if method == "think":
+                lay = out.past_key_values.layers[1]
+                k = int(128 * extra["ratio"])
+                assert isinstance(lay, ThinkDynamicLayer) and tuple(lay.key_pruned.shape) == (1, 32, 80 - 16, 128 - k)
+                assert lay.keys.shape[2] == 16 + 3 and lay.values.shape[2] == 80 + 3 and lay.get_seq_length() == 400 + 3
+    finally:
+        mp.replace_llama("fullkv")
+    a, b = logits[("snapkv", None)], logits[("think", 0.0)]
+    assert torch.isfinite(logits[("think", 0.4)]).all()
+    assert float((a - b).abs().max()) < 3e-2 * max(1.0, float(a.abs().max()))

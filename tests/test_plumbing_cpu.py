@@ -515,3 +515,32 @@ def test_pivot_merge_through_the_model(cpu_backend):
         assert cache.get_seq_length() == 96 + 2
     finally:
         mp.replace_llama("fullkv")
+
+
+def test_think_through_the_model(cpu_backend):
+    """replace_llama("think") (monkeypatch.py:80-83): prefill stores channel-pruned keys + recent keys + mask + values in a
+    ThinkDynamicLayer, decode attends over both parts (llama_model_think.py:167-196).  With ratio = 0 nothing is pruned and
+    the generated tokens must equal plain SnapKV's; with ratio = 0.4 the cache has the reference's shapes."""
+    from kvcache_factory_amd.cache import ThinkDynamicLayer
+    ids = torch.randint(0, 512, (1, 96))
+    knobs = dict(window_size=8, max_capacity_prompt=40, kernel_size=7, pooling="maxpool")
+    seqs = {}
+    try:
+        for method, extra in (("snapkv", {}), ("think", dict(recent_size=16, ratio=0.0)), ("think", dict(recent_size=16, ratio=0.4))):
+            mp.replace_llama("fullkv"); mp.replace_llama(method)
+            model = _llama(layers=2)
+            _set_knobs(model, **knobs, **extra)
+            out = _generate(model, ids, 4)
+            seqs[(method, extra.get("ratio"))] = out.sequences
+            if method == "think":
+                layer = out.past_key_values.layers[0]
+                assert isinstance(layer, ThinkDynamicLayer)
+                k = int(128 * extra["ratio"])
+                assert tuple(layer.key_pruned.shape) == (1, 32, 40 - 16, 128 - k) and tuple(layer.mask.shape) == (1, 32, 128)
+                assert layer.keys.shape[2] == 16 + 3 and layer.values.shape[2] == 40 + 3 and layer.get_seq_length() == 96 + 3
+                assert int(layer.mask.sum()) == 32 * (128 - k)
+        assert torch.equal(seqs[("snapkv", None)], seqs[("think", 0.0)])
+        with pytest.raises(NotImplementedError):
+            mp.replace_mistral("think")
+    finally:
+        mp.replace_llama("fullkv")
