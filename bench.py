@@ -9,7 +9,7 @@ utilisation sampler and its wall clock can see them), cycling over `--sets` dist
 set (0.5 GB per prompt at 8k) is never cache resident.  tokens/step = prompts * q_len * 32 layers.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2_w32|c3|c4|c5] [--tie-mode torch_cpu|canonical]
-                    [--mode batch|calls] [--in-flight 1|2]
+                    [--mode batch|calls] [--in-flight 1..4]
 
 N > 1 (torchrun, one rank per GPU): the path shards by independent prompts/layers with no exchange, so every rank
 runs its own replica of the workload (weak scaling); time = max over ranks, value = N * tokens / time.
@@ -338,7 +338,7 @@ def main():
     ap.add_argument("--mode", default="batch", choices=["batch", "calls"],
                     help="batch: one kvc_compress_batch call per prompt (all 32 layers per kernel launch); "
                          "calls: 32 kvc_compress calls per prompt spread over --streams streams")
-    ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
+    ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2, 3, 4],
                     help="prompts in flight: 2 alternates consecutive prompts between two HIP streams (a serving stack's overlap: "
                          "the latency-bound exact top-k of one prompt runs beside the K scan of the next)")
     ap.add_argument("--prompts", type=int, default=0, help="prompts per step (0: the config's default, sized for ~20 ms steps)")
@@ -373,9 +373,9 @@ def main():
     ks = layer_budgets(cfg)
     n_sets = max(a.sets or cfg.get("sets", 2), a.in_flight)
     inputs = [make_inputs(cfg, dev, rank_seed(rank) + 100 * s) for s in range(n_sets)]
-    fl = side_streams(dev, 2) if a.in_flight == 2 else None
+    fl = side_streams(dev, a.in_flight) if a.in_flight > 1 else None
     prompts = [Prompt(cfg, dev, a.tie_mode, a.mode, inputs[s], ks, a.streams if a.mode == "calls" else 1,
-                      stream=fl[s % 2] if fl else None) for s in range(n_sets)]
+                      stream=fl[s % len(fl)] if fl else None) for s in range(n_sets)]
     used = list(fl or ()) + (prompts[0].streams if a.mode == "calls" and a.streams > 1 else [])
     for p in prompts:
         p.run()                                            # first call outside the timed region (one-time attribute setup)
@@ -459,17 +459,20 @@ def main():
             except Exception as e:
                 extra[f"tie_mode_{other}_error"] = str(e)
             if a.in_flight == 1 and a.mode == "batch":
-                try:        # two prompts in flight: own stream, outputs and workspace each; with parity counters of its own
-                    s2 = side_streams(dev, 2)
-                    pf = [Prompt(cfg, dev, a.tie_mode, "batch", inputs[s], ks, stream=s2[s % 2]) for s in range(n_sets)]
-                    extra["tokens_per_s_two_prompts_in_flight"] = quick(pf, s2)
-                    torch.cuda.synchronize(dev)
-                    same = all(torch.equal(x, y) for pa, pb in zip(pf, prompts) for x, y in
-                               zip(pa.bp.k_out + pa.bp.v_out + pa.bp.idx, pb.bp.k_out + pb.bp.v_out + pb.bp.idx))
-                    extra["two_prompts_in_flight_outputs_identical_to_single_stream"] = bool(same)
-                    del pf
-                except Exception as e:
-                    extra["two_in_flight_error"] = str(e)
+                for n_fl, word in ((2, "two"), (3, "three")):
+                    try:    # several prompts in flight: own stream, outputs and workspace each; outputs compared with the single-stream run
+                        sn = side_streams(dev, n_fl)
+                        xin = [inputs[s % n_sets] for s in range(max(n_sets, n_fl))]
+                        pf = [Prompt(cfg, dev, a.tie_mode, "batch", xin[s], ks, stream=sn[s % n_fl]) for s in range(len(xin))]
+                        extra[f"tokens_per_s_{word}_prompts_in_flight"] = quick(pf, sn)
+                        torch.cuda.synchronize(dev)
+                        same = all(torch.equal(x, y) for i, pa in enumerate(pf) for x, y in
+                                   zip(pa.bp.k_out + pa.bp.v_out + pa.bp.idx,
+                                       prompts[i % n_sets].bp.k_out + prompts[i % n_sets].bp.v_out + prompts[i % n_sets].bp.idx))
+                        extra[f"{word}_prompts_in_flight_outputs_identical_to_single_stream"] = bool(same)
+                        del pf
+                    except Exception as e:
+                        extra[f"{word}_in_flight_error"] = str(e)
             if a.mode == "batch" and a.dot_mode == "exact":
                 try:
                     extra["tokens_per_s_dot_mode_mfma16_tolerance_mode"] = quick(
