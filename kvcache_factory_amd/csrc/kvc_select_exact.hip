@@ -21,6 +21,7 @@
 #include "kvc_common.h"
 #include "kvc_launch.h"
 #include "kvc_stl_emul.h"
+#include <type_traits>
 
 namespace kvc {
 
@@ -259,12 +260,25 @@ typedef __attribute__((address_space(3))) int lds_int;
 typedef __attribute__((address_space(1))) int glb_int;
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 typedef __attribute__((address_space(1))) int64_t glb_i64;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+// Element access: 64-bit (key << 32 | index) nodes, or — lds_u32: 16-bit dtypes, rows up to 65 536, array in LDS — the same
+// node packed as (key << 16 | index) in 32 bits: half the LDS, so that twice as many workgroups stay resident per CU.
+template <class AP> struct NodeIO {
+    __device__ __forceinline__ static u64 ld(const AP* p, int i) { return (u64)p[i]; }
+    __device__ __forceinline__ static void st(AP* p, int i, u64 v) { p[i] = v; }
+    __device__ __forceinline__ static uint32_t key(const AP* p, int i) { return (uint32_t)((u64)p[i] >> 32); }
+};
+template <> struct NodeIO<lds_u32> {
+    __device__ __forceinline__ static u64 ld(const lds_u32* p, int i) { const uint32_t x = p[i]; return ((u64)(x >> 16) << 32) | (x & 0xffffu); }
+    __device__ __forceinline__ static void st(lds_u32* p, int i, u64 v) { p[i] = ((uint32_t)(v >> 32) << 16) | ((uint32_t)v & 0xffffu); }
+    __device__ __forceinline__ static uint32_t key(const lds_u32* p, int i) { return p[i] >> 16; }
+};
 template <class AP>
 struct ArrT {                // the view kvc_stl_emul.h's routines take, on an address-space-typed array
     AP* p;
-    __device__ __forceinline__ u64 get(int i) const { return uni((u64)p[i]); }
-    __device__ __forceinline__ void set(int i, u64 v) const { p[i] = v; }
-    __device__ __forceinline__ void swap(int i, int j) const { const u64 a = get(i), b = get(j); p[i] = b; p[j] = a; }
+    __device__ __forceinline__ u64 get(int i) const { return uni(NodeIO<AP>::ld(p, i)); }
+    __device__ __forceinline__ void set(int i, u64 v) const { NodeIO<AP>::st(p, i, v); }
+    __device__ __forceinline__ void swap(int i, int j) const { const u64 a = get(i), b = get(j); set(i, b); set(j, a); }
 };
 template <class AP>
 struct WaveSel {
@@ -279,7 +293,8 @@ struct WaveSel {
     unsigned long long* xstamps_ = nullptr;              // the kernel's stamp array (diagnostic build)
 #endif
     __device__ __forceinline__ static uint32_t key(u64 v) { return (uint32_t)(v >> 32); }
-    __device__ __forceinline__ u64 get(int i) const { return uni(arr[i]); }
+    typedef NodeIO<AP> IO;
+    __device__ __forceinline__ u64 get(int i) const { return uni(IO::ld(arr, i)); }
 
     // ONE pass over [first, last): left stoppers (!(key > pk)) in ascending position order, capped at `cap` entries; right
     // stoppers (!(pk > key)) in ascending order too, into a ring of `ring` >= max(cap, 64) slots, so that the serial scan's
@@ -289,7 +304,7 @@ struct WaveSel {
         for (int base = first; base < last; base += 64 * UF) {
             uint32_t kx[UF];
 #pragma unroll
-            for (int u = 0; u < UF; ++u) { const int i = base + u * 64 + lane; kx[u] = i < last ? key(arr[i]) : 0u; }
+            for (int u = 0; u < UF; ++u) { const int i = base + u * 64 + lane; kx[u] = i < last ? IO::key(arr, i) : 0u; }
 #pragma unroll
             for (int u = 0; u < UF; ++u) {
                 const int i = base + u * 64 + lane;
@@ -326,9 +341,9 @@ struct WaveSel {
                 r[u] = t < T ? first + r_at(Rr, nrm, ring, t) : -1;
             }
 #pragma unroll
-            for (int u = 0; u < US; ++u) if (l[u] >= 0) { av[u] = arr[l[u]]; bv[u] = arr[r[u]]; }
+            for (int u = 0; u < US; ++u) if (l[u] >= 0) { av[u] = IO::ld(arr, l[u]); bv[u] = IO::ld(arr, r[u]); }
 #pragma unroll
-            for (int u = 0; u < US; ++u) if (l[u] >= 0) { arr[l[u]] = bv[u]; arr[r[u]] = av[u]; }
+            for (int u = 0; u < US; ++u) if (l[u] >= 0) { IO::st(arr, l[u], bv[u]); IO::st(arr, r[u], av[u]); }
         }
     }
     template <class LT>
@@ -399,7 +414,7 @@ struct WaveSel {
     }
     __device__ __forceinline__ int partition_pivot_small_body(int first, int last) {
         const int m = last - first;                                       // 4 .. 64
-        u64 x = lane < m ? arr[first + lane] : 0ull;
+        u64 x = lane < m ? IO::ld(arr, first + lane) : 0ull;
         // __move_median_to_first(first, first + 1, mid, last - 1)
         const int ia = 1, ib = m / 2, ic = m - 1;
         const u64 va = rd64(x, ia), vb = rd64(x, ib), vc = rd64(x, ic);
@@ -431,7 +446,7 @@ struct WaveSel {
         const uint32_t plo = (uint32_t)__builtin_amdgcn_ds_bpermute(partner << 2, (int)(uint32_t)x);
         const uint32_t phi = (uint32_t)__builtin_amdgcn_ds_bpermute(partner << 2, (int)(uint32_t)(x >> 32));
         x = ((u64)phi << 32) | plo;
-        if (lane < m) arr[first + lane] = x;
+        if (lane < m) IO::st(arr, first + lane, x);
         __syncthreads();
         return first + (lnext < rlast ? lnext : rlast);
     }
@@ -450,7 +465,7 @@ struct WaveSel {
     // fallback), same moves as the scalar program.  A 64-element range costs 2-4 steps instead of 3-7 partitions.
     __device__ __forceinline__ void sort64_body(int first, int last, int d) {
         const int m = last - first;                                       // 17 .. 64
-        u64 x = lane < m ? arr[first + lane] : 0ull;
+        u64 x = lane < m ? IO::ld(arr, first + lane) : 0ull;
         int sf = lane < m ? 0 : lane, sl = lane < m ? m : lane;           // lanes beyond the range: empty segments
         bool done = false;
         u64 bailed = 0;                                                   // first lanes of segments left to the heap sort
@@ -502,7 +517,7 @@ struct WaveSel {
                 if (lane < cut) sl = cut; else sf = cut;
             }
         }
-        if (lane < m) arr[first + lane] = x;
+        if (lane < m) IO::st(arr, first + lane, x);
         __syncthreads();
         Arr A{arr};
         while (bailed) {                                                  // __partial_sort(f, l, l) = heap_select + sort_heap
@@ -559,10 +574,10 @@ struct WaveSel {
 #pragma unroll
             for (int dlt = 1; dlt < 16; ++dlt) {
                 const int jb = ic - dlt, ja = ic + dlt;
-                kb[dlt - 1] = key(arr[jb >= first ? jb : first]);
-                ka[dlt - 1] = key(arr[ja < last ? ja : last - 1]);
+                kb[dlt - 1] = IO::key(arr, jb >= first ? jb : first);
+                ka[dlt - 1] = IO::key(arr, ja < last ? ja : last - 1);
             }
-            const u64 v = arr[ic];
+            const u64 v = IO::ld(arr, ic);
             const uint32_t ki = key(v);
             int pos = ic;
 #pragma unroll
@@ -939,27 +954,36 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const SelectArgs a, u6
 #endif
         u64 nth;
         if (arr_in_lds) {
-            for (int i = lane; i < n; i += 64) larr[i] = ((u64)Key<DT>::of(s[i]) << 32) | (uint32_t)i;
-            __syncthreads();
-            WaveSel<lds_u64> S{larr, lists, lists + (n / 2 + 2), small, lane};
-            S.small_bytes = list_bytes;
+            auto run = [&](auto* arr_t, lds_int* small_t) {
+                typedef typename std::remove_pointer<decltype(arr_t)>::type AP;
+                for (int i = lane; i < n; i += 64) NodeIO<AP>::st(arr_t, i, ((u64)Key<DT>::of(s[i]) << 32) | (uint32_t)i);
+                __syncthreads();
+                WaveSel<AP> S{arr_t, lists, lists + (n / 2 + 2), small_t, lane};
+                S.small_bytes = list_bytes;
 #if defined(KVC_STAMPS)
-            S.xstamps_ = xsa;
+                S.xstamps_ = xsa;
 #endif
-            KVC_XSTAMP(0);
-            if (k - 1 != n) S.introselect(0, k - 1, n, lg_(n) * 2);          // std::nth_element(first, first + k - 1, last)
+                KVC_XSTAMP(0);
+                if (k - 1 != n) S.introselect(0, k - 1, n, lg_(n) * 2);      // std::nth_element(first, first + k - 1, last)
 #if defined(KVC_STAMPS)
-            xstamps_[10] = xsa[8]; xstamps_[11] = xsa[9];
-            for (int i = 0; i < 4; ++i) xstamps_[16 + i] = xsa[12 + i];
+                xstamps_[10] = xsa[8]; xstamps_[11] = xsa[9];
+                for (int i = 0; i < 4; ++i) xstamps_[16 + i] = xsa[12 + i];
 #endif
-            KVC_XSTAMP(1);
-            nth = larr[k - 1];
-            KVC_XSTAMP(2);
-            S.sort_to(0, k - 1, lstack, gout);                               // std::sort(first, first + k - 1), straight to out
+                KVC_XSTAMP(1);
+                nth = NodeIO<AP>::ld(arr_t, k - 1);
+                KVC_XSTAMP(2);
+                S.sort_to(0, k - 1, lstack, gout);                           // std::sort(first, first + k - 1), straight to out
 #if defined(KVC_STAMPS)
-            xstamps_[3] = xsa[3]; xstamps_[8] = xsa[8]; xstamps_[9] = xsa[9];
-            for (int i = 12; i < 16; ++i) xstamps_[i] = xsa[i];
+                xstamps_[3] = xsa[3]; xstamps_[8] = xsa[8]; xstamps_[9] = xsa[9];
+                for (int i = 12; i < 16; ++i) xstamps_[i] = xsa[i];
 #endif
+            };
+            if ((arr_in_lds & 2) != 0) {                                     // packed 32-bit nodes (16-bit dtypes, n <= 65536)
+                lds_u32* const parr = (lds_u32*)lds_arr;
+                run(parr, (lds_int*)(parr + ((n + 1) & ~1)));
+            } else {
+                run(larr, small);
+            }
         } else {
             glb_u64* const garr = (glb_u64*)hs;
             for (int i = lane; i < n; i += 64) garr[i] = ((u64)Key<DT>::of(s[i]) << 32) | (uint32_t)i;
@@ -1031,7 +1055,8 @@ static int launch_exact_t(const SelectArgs& a, void* scratch, hipStream_t st) {
     // being sorted; behind it the list region of the partitions, as large as the resident workgroups per CU allow (160 KB
     // of LDS, one wave = one workgroup here: these kernels are latency-bound, a second round of workgroups doubles
     // their time) up to what the longest range needs
-    size_t body = (in_lds && any_nth) ? (size_t)a.n * 8 : (size_t)a.k_max * 8;
+    const bool packed = in_lds && any_nth && Key<DT>::bits == 16 && a.n <= 65536;
+    size_t body = (in_lds && any_nth) ? (packed ? (size_t)((a.n + 1) & ~1) * 4 : (size_t)a.n * 8) : (size_t)a.k_max * 8;
     if (body < kWaveHeap9Lds) body = kWaveHeap9Lds;
     if (body < kWaveHeapLds) body = kWaveHeapLds;                   // 64-bit nodes (fp32, or n > 65536)
     const size_t list_bytes = any_nth ? list_region_bytes(1152 + body, a.n) : 0;
@@ -1040,7 +1065,7 @@ static int launch_exact_t(const SelectArgs& a, void* scratch, hipStream_t st) {
     static LdsCache lds_cache = {};
     if (ensure_lds(reinterpret_cast<const void*>(&select_exact_kernel<DT>), lds, lds_cache) != 0) return KVC_ERR_HIP;
     hipLaunchKernelGGL((select_exact_kernel<DT>), dim3((unsigned)a.heads, (unsigned)a.n_items), dim3(64), lds, st, a,
-                       reinterpret_cast<u64*>(scratch), in_lds, (int)list_bytes);
+                       reinterpret_cast<u64*>(scratch), in_lds | (packed ? 2 : 0), (int)list_bytes);
     return 0;
 }
 
