@@ -260,7 +260,8 @@ int kvc_l2norm_compress(const kvc_params* p, const void* k, const void* v, void*
  * top-k (kvc_select / kvc_compress idx_out).  Outputs [b][n_q_heads][k + window][D]: k_out in the reference's key order
  * [window rows, selected rows], v_out in its value order [selected rows, window rows] (the reference's two cats differ, :145 / :147,
  * and the pivot found on the key order is applied to both).  head_dim must be 128 (hard-coded in the reference, :149);
- * 16-bit dtypes.  pivot_out ([b*n_q_heads][q_len] int32: row [0, drop_len) = pivot of every dropped token, ascending position)
+ * 16-bit dtypes.  bsz > 1: the union of selections is taken per batch row (the reference flattens its isin over the batch
+ * too, :131-134, and is only ever run with bsz = 1, README.md:29).  pivot_out ([b*n_q_heads][q_len] int32: row [0, drop_len) = pivot of every dropped token, ascending position)
  * and drop_len_out ([b] int32) may be NULL.  Arithmetic: see csrc/kvc_merge.hip.  Workspace: kvc_merge_workspace_bytes(p). */
 size_t kvc_merge_workspace_bytes(const kvc_params* p);
 int kvc_merge_pivot(const kvc_params* p, const void* k, const void* v, const int64_t* idx, void* k_out, void* v_out,

@@ -1239,3 +1239,18 @@ def test_think_patched_model_on_gpu(kvc, gpu_device, monkeypatch):
     a, b = logits[("snapkv", None)], logits[("think", 0.0)]
     assert torch.isfinite(logits[("think", 0.4)]).all()
     assert float((a - b).abs().max()) < 3e-2 * max(1.0, float(a.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,W,keep,dtype", [(4000, 32, 2016, torch.bfloat16), (700, 8, 3, torch.float16), (300, 64, 200, torch.bfloat16)])
+def test_merge_pivot_shapes_vs_oracle(kvc, oracle, gpu_device, L, W, keep, dtype):
+    """kvc_merge_pivot against the oracle where the fixtures do not reach: thousands of kept rows (the kept keys pass through LDS
+    128 rows at a time with a running first maximum), a handful of kept rows (one partial M-tile), and almost everything kept
+    (few dropped tokens: workgroups beyond drop_len exit at once).  Indices = an exact-tie top-k of random scores per head."""
+    q, k, v = G.synth.make_qkv(4, 2, L, 128, dtype, 5150 + L)
+    g = torch.Generator().manual_seed(L + keep)
+    idx = torch.stack([torch.randperm(L - W, generator=g)[:keep] for _ in range(4)]).contiguous()
+    ko_o, vo_o, piv_o = oracle.merge_pivot(k, v, idx, W)
+    ko, vo, piv = kvc.merge_pivot(kvc.SNAPKV, k.to(gpu_device), v.to(gpu_device), idx[None].to(gpu_device), W, return_pivot=True)
+    assert torch.equal(piv[0].cpu(), piv_o)
+    assert torch.equal(G.bits(ko.cpu()), G.bits(ko_o)) and torch.equal(G.bits(vo.cpu()), G.bits(vo_o))
