@@ -268,11 +268,14 @@ template <class AP> struct NodeIO {
     __device__ __forceinline__ static void st(AP* p, int i, u64 v) { p[i] = v; }
     __device__ __forceinline__ static uint32_t key(const AP* p, int i) { return (uint32_t)((u64)p[i] >> 32); }
 };
-template <> struct NodeIO<lds_u32> {
-    __device__ __forceinline__ static u64 ld(const lds_u32* p, int i) { const uint32_t x = p[i]; return ((u64)(x >> 16) << 32) | (x & 0xffffu); }
-    __device__ __forceinline__ static void st(lds_u32* p, int i, u64 v) { p[i] = ((uint32_t)(v >> 32) << 16) | ((uint32_t)v & 0xffffu); }
-    __device__ __forceinline__ static uint32_t key(const lds_u32* p, int i) { return p[i] >> 16; }
+typedef __attribute__((address_space(1))) uint32_t glb_u32;
+template <class P32> struct NodeIO32 {
+    __device__ __forceinline__ static u64 ld(const P32* p, int i) { const uint32_t x = p[i]; return ((u64)(x >> 16) << 32) | (x & 0xffffu); }
+    __device__ __forceinline__ static void st(P32* p, int i, u64 v) { p[i] = ((uint32_t)(v >> 32) << 16) | ((uint32_t)v & 0xffffu); }
+    __device__ __forceinline__ static uint32_t key(const P32* p, int i) { return p[i] >> 16; }
 };
+template <> struct NodeIO<lds_u32> : NodeIO32<lds_u32> {};
+template <> struct NodeIO<glb_u32> : NodeIO32<glb_u32> {};      // the workspace copy of a long row: half the bytes to scan and to swap
 template <class AP>
 struct ArrT {                // the view kvc_stl_emul.h's routines take, on an address-space-typed array
     AP* p;
@@ -329,7 +332,10 @@ struct WaveSel {
         if (e < 0) e += ring;
         return (int)Rr[e];
     }
-    template <class LT, int US>
+    // LEFT_ONLY (nth_element about to continue in [first, cut)): everything at and beyond the cut is never read again — the
+    // selection only ever narrows around nth and the caller sorts [0, nth) afterwards — so the right-hand halves of the swaps
+    // (a random read and a random write each) are skipped.
+    template <class LT, int US, bool LEFT_ONLY>
     __device__ __forceinline__ void swap_pairs(int first, int T, const LT* Lp, const LT* Rr, int nrm, int ring) {
         for (int t0 = 0; t0 < T; t0 += 64 * US) {
             int l[US], r[US];
@@ -341,13 +347,19 @@ struct WaveSel {
                 r[u] = t < T ? first + r_at(Rr, nrm, ring, t) : -1;
             }
 #pragma unroll
-            for (int u = 0; u < US; ++u) if (l[u] >= 0) { av[u] = IO::ld(arr, l[u]); bv[u] = IO::ld(arr, r[u]); }
+            for (int u = 0; u < US; ++u) if (l[u] >= 0) { if (!LEFT_ONLY) av[u] = IO::ld(arr, l[u]); bv[u] = IO::ld(arr, r[u]); }
 #pragma unroll
-            for (int u = 0; u < US; ++u) if (l[u] >= 0) { IO::st(arr, l[u], bv[u]); IO::st(arr, r[u], av[u]); }
+            for (int u = 0; u < US; ++u) if (l[u] >= 0) { IO::st(arr, l[u], bv[u]); if (!LEFT_ONLY) IO::st(arr, r[u], av[u]); }
         }
     }
+    template <class LT, bool LEFT_ONLY>
+    __device__ __forceinline__ void swap_all(int first, int T, const LT* Lp, const LT* Rr, int nrm, int ring) {
+        if (T > 2048) swap_pairs<LT, 8, LEFT_ONLY>(first, T, Lp, Rr, nrm, ring);
+        else if (T > 128) swap_pairs<LT, 2, LEFT_ONLY>(first, T, Lp, Rr, nrm, ring);
+        else swap_pairs<LT, 1, LEFT_ONLY>(first, T, Lp, Rr, nrm, ring);
+    }
     template <class LT>
-    __device__ __forceinline__ int partition_t(int first, int last, uint32_t pk, LT* Lp, LT* Rr) {
+    __device__ __forceinline__ int partition_t(int first, int last, uint32_t pk, LT* Lp, LT* Rr, int nth) {
         const int m = last - first, cap = m / 2 + 2, ring = cap > 64 ? cap : 64;
         int NL = 0, NR = 0, nrm = 0;
         KVC_XTIC(x0_);
@@ -384,24 +396,24 @@ struct WaveSel {
         }
         KVC_XTIC(x2_);
         KVC_XACC(13, x1_, x2_);
-        if (T > 2048) swap_pairs<LT, 8>(first, T, Lp, Rr, nrm, ring);
-        else if (T > 128) swap_pairs<LT, 2>(first, T, Lp, Rr, nrm, ring);
-        else swap_pairs<LT, 1>(first, T, Lp, Rr, nrm, ring);
         const int lnext = T < NL ? first + uni((int)Lp[T]) : 0x7fffffff;
         const int rlast = T > 0 ? first + uni(r_at(Rr, nrm, ring, T - 1)) : 0x7fffffff;
+        const int cut = lnext < rlast ? lnext : rlast;
+        if (nth >= 0 && cut > nth) swap_all<LT, true>(first, T, Lp, Rr, nrm, ring);
+        else swap_all<LT, false>(first, T, Lp, Rr, nrm, ring);
         __syncthreads();
         KVC_XTIC(x3_);
         KVC_XACC(14, x2_, x3_);
-        return lnext < rlast ? lnext : rlast;
+        return cut;
     }
-    __device__ __forceinline__ int partition(int first, int last, int pivot) {
+    __device__ __forceinline__ int partition(int first, int last, int pivot, int nth) {
         const uint32_t pk = key(get(pivot));
         const int m = last - first, cap = m / 2 + 2;
         if (m <= 65536 && list_bytes_for(m) <= (size_t)small_bytes) {
             lds_u16* const l16 = (lds_u16*)small;
-            return partition_t<lds_u16>(first, last, pk, l16, l16 + cap);
+            return partition_t<lds_u16>(first, last, pk, l16, l16 + cap, nth);
         }
-        return partition_t<glb_int>(first, last, pk, Lbig, Rbig);
+        return partition_t<glb_int>(first, last, pk, Lbig, Rbig, nth);
     }
     // __unguarded_partition_pivot of a range of at most 64 elements (most calls of the sort phase), one element per lane
     // in registers: median-of-three and its swap by readlane, the two stopper sets as ballots, the pairing by popcounts
@@ -534,8 +546,9 @@ struct WaveSel {
     // `this`, a pointer to the object in scratch memory, and reload every field through flat loads.
     static __device__ __noinline__ int partition_pivot_small(WaveSel S, int first, int last) { return S.partition_pivot_small_body(first, last); }
     static __device__ __noinline__ void sort64(WaveSel S, int first, int last, int d) { S.sort64_body(first, last, d); }
-    static __device__ __noinline__ int partition_pivot(WaveSel S, int first, int last) { return S.partition_pivot_body(first, last); }
-    __device__ __forceinline__ int partition_pivot_body(int first, int last) {   // __unguarded_partition_pivot
+    // nth >= 0: called by nth_element, which continues on the side that holds nth (see swap_pairs); -1: both sides are needed
+    static __device__ __noinline__ int partition_pivot(WaveSel S, int first, int last, int nth) { return S.partition_pivot_body(first, last, nth); }
+    __device__ __forceinline__ int partition_pivot_body(int first, int last, int nth) {   // __unguarded_partition_pivot
         if (last - first <= 64) { KVC_XCOUNT(8); return partition_pivot_small(*this, first, last); }
         KVC_XCOUNT(9);
         const int mid = first + (last - first) / 2;
@@ -545,7 +558,7 @@ struct WaveSel {
         __syncthreads();
         KVC_XTIC(m1_);
         KVC_XACC(15, m0_, m1_);
-        return partition(first + 1, last, first);
+        return partition(first + 1, last, first, nth);
     }
     __device__ __forceinline__ void introselect(int first, int nth, int last, int depth_limit) {
         Arr A{arr};
@@ -557,7 +570,7 @@ struct WaveSel {
                 return;
             }
             --depth_limit;
-            const int cut = partition_pivot(*this, first, last);
+            const int cut = partition_pivot(*this, first, last, nth);
             if (cut <= nth) first = cut; else last = cut;
         }
         insertion_sort_(A, first, last);
@@ -604,7 +617,7 @@ struct WaveSel {
                 }
                 if (l - f <= 64) { sort64(*this, f, l, d); break; }           // the whole subtree, in registers
                 --d;
-                const int cut = partition_pivot(*this, f, l);
+                const int cut = partition_pivot(*this, f, l, -1);
                 if (lane == 0) { stack[3 * sp] = cut; stack[3 * sp + 1] = l; stack[3 * sp + 2] = d; }
                 ++sp;
                 l = cut;
@@ -640,7 +653,7 @@ struct WaveSel {
                 }
                 if (l - f <= 64) { sort64(*this, f, l, d); break; }
                 --d;
-                const int cut = partition_pivot(*this, f, l);
+                const int cut = partition_pivot(*this, f, l, -1);
                 if (cut < first + want) {                                  // the right part still reaches into the prefix
                     if (lane == 0) { stack[3 * sp] = cut; stack[3 * sp + 1] = l; stack[3 * sp + 2] = d; }
                     ++sp;
@@ -978,33 +991,42 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const SelectArgs a, u6
                 for (int i = 12; i < 16; ++i) xstamps_[i] = xsa[i];
 #endif
             };
-            if ((arr_in_lds & 2) != 0) {                                     // packed 32-bit nodes (16-bit dtypes, n <= 65536)
-                lds_u32* const parr = (lds_u32*)lds_arr;
-                run(parr, (lds_int*)(parr + ((n + 1) & ~1)));
+            if constexpr (Key<DT>::bits == 16) {
+                if ((arr_in_lds & 2) != 0) {                                 // packed 32-bit nodes (16-bit dtypes, n <= 65536)
+                    lds_u32* const parr = (lds_u32*)lds_arr;
+                    run(parr, (lds_int*)(parr + ((n + 1) & ~1)));
+                } else {
+                    run(larr, small);
+                }
             } else {
                 run(larr, small);
             }
         } else {
-            glb_u64* const garr = (glb_u64*)hs;
-            for (int i = lane; i < n; i += 64) garr[i] = ((u64)Key<DT>::of(s[i]) << 32) | (uint32_t)i;
-            __syncthreads();
-            WaveSel<glb_u64> S{garr, lists, lists + (n / 2 + 2), (lds_int*)larr, lane};
-            S.small_bytes = list_bytes + a.k_max * 8;
+            auto run = [&](auto* garr) {
+                typedef typename std::remove_pointer<decltype(garr)>::type AP;
+                for (int i = lane; i < n; i += 64) NodeIO<AP>::st(garr, i, ((u64)Key<DT>::of(s[i]) << 32) | (uint32_t)i);
+                __syncthreads();
+                WaveSel<AP> S{garr, lists, lists + (n / 2 + 2), (lds_int*)larr, lane};
+                S.small_bytes = list_bytes + a.k_max * 8;
 #if defined(KVC_STAMPS)
-            S.xstamps_ = xsa;
+                S.xstamps_ = xsa;
 #endif
-            KVC_XSTAMP(0);
-            if (k - 1 != n) S.introselect(0, k - 1, n, lg_(n) * 2);
+                KVC_XSTAMP(0);
+                if (k - 1 != n) S.introselect(0, k - 1, n, lg_(n) * 2);
 #if defined(KVC_STAMPS)
-            xstamps_[10] = xsa[8]; xstamps_[11] = xsa[9];
-            for (int i = 0; i < 4; ++i) xstamps_[16 + i] = xsa[12 + i];
+                xstamps_[10] = xsa[8]; xstamps_[11] = xsa[9];
+                for (int i = 0; i < 4; ++i) xstamps_[16 + i] = xsa[12 + i];
 #endif
-            KVC_XSTAMP(1);
-            // The k - 1 leading elements move to LDS for the sort: it makes hundreds of small partitions, each a handful of
-            // dependent accesses — a memory round trip apiece on the workspace copy.
-            nth = garr[k - 1];
-            for (int i = lane; i < k - 1; i += 64) larr[i] = garr[i];
-            __syncthreads();
+                KVC_XSTAMP(1);
+                // The k - 1 leading elements move to LDS for the sort: it makes hundreds of small partitions, each a handful of
+                // dependent accesses — a memory round trip apiece on the workspace copy.
+                nth = NodeIO<AP>::ld(garr, k - 1);
+                for (int i = lane; i < k - 1; i += 64) larr[i] = NodeIO<AP>::ld(garr, i);
+                __syncthreads();
+            };
+            // (Packed 32-bit nodes in the workspace were measured: the swaps gain 12 %, but the scan is latency-bound and each of its
+            // loads then carries half the bytes — 242 -> 518 us at 32k.  64-bit nodes stay.)
+            run((glb_u64*)hs);
             WaveSel<lds_u64> S2{larr, lists, lists + (n / 2 + 2), small, lane};
             S2.small_bytes = list_bytes;
 #if defined(KVC_STAMPS)
