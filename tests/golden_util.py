@@ -20,11 +20,27 @@ def names(pred=lambda m: True):
     return sorted(n for n, m in MANIFEST.items() if pred(m))
 
 
+_INPUT_CACHE = {}
+
+
+def _make_qkv_cached(Hq, Hkv, L, D, dtype, seed, peaky, expanded, device):
+    """The big fixtures (8k x 32 heads, 32k) share their inputs (same seed and geometry): generate each once per process.
+    Tests treat the tensors as read-only."""
+    key = (Hq, Hkv, L, D, dtype, seed, peaky, expanded, str(device))
+    if key not in _INPUT_CACHE:
+        if L * Hq < 64 * 1024:                               # small cases are cheap: no point in holding them
+            return synth.make_qkv(Hq, Hkv, L, D, dtype, seed, peaky=peaky, expanded=expanded, device=device)
+        if len(_INPUT_CACHE) >= 4:
+            _INPUT_CACHE.pop(next(iter(_INPUT_CACHE)))
+        _INPUT_CACHE[key] = synth.make_qkv(Hq, Hkv, L, D, dtype, seed, peaky=peaky, expanded=expanded, device=device)
+    return _INPUT_CACHE[key]
+
+
 def inputs(meta, device="cpu", expanded=True):
     """Regenerate (q, k, v) of a fixture exactly as oracle/gen_golden.py fed them to the reference."""
     dtype = DT[meta["dtype"]]
-    q, k, v = synth.make_qkv(meta["Hq"], meta["Hkv"], meta["L"], meta["D"], dtype, meta["seed"],
-                             peaky=meta.get("peaky", False), expanded=expanded, device=device)
+    q, k, v = _make_qkv_cached(meta["Hq"], meta["Hkv"], meta["L"], meta["D"], dtype, meta["seed"],
+                               meta.get("peaky", False), expanded, device)
     if meta.get("zero_q"):
         q = torch.zeros_like(q)
     if meta.get("scale_q"):
