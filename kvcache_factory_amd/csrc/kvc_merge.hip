@@ -15,7 +15,7 @@
 //   merge_pivot_kernel    the cosines on the f32 MFMA (32 dropped tokens per wave x 128 kept rows per LDS stage; 64
 //                         v_mfma_f32_32x32x2_f32 per block = the d-ascending fp32 chain: products of two 16-bit values are exact
 //                         in fp32), rounded to the dtype, first maximum
-//   merge_reduce_kernel   one wave per (head, kept row, K|V): walks the pivots 64 at a time (ballot -> ascending order), adds the
+//   merge_reduce_kernel   one wave per (head, kept row) for K and V together: walks the pivots 64 at a time (ballot -> ascending order), adds the
 //                         merged rows in fp32, then sum -> dtype, count -> dtype, quotient -> dtype
 // Arithmetic = oracle/kvc_oracle.cpp kvco_merge_pivot (norms in torch's 8-accumulator order, fp32 divides, one rounding each),
 // which equals the imported reference bit for bit on every fixture (tests/golden/merge_*).
@@ -110,16 +110,17 @@ __global__ __launch_bounds__(64) void merge_kept_kernel(const MergeArgs a) {
 
 // grid = (ceil(q_len / 128), bsz * H_q), block = 256 = 4 waves: pivot[hb][p] for p < drop_len[b].
 // Each wave owns 32 dropped tokens (the B operand of v_mfma_f32_32x32x2_f32: lane (kh, j) keeps the elements d = 2s + kh of
-// its token j, normalised, in 64 registers); the kept rows are the A operand, 128 rows at a time through LDS (de-interleaved:
+// its token j, normalised, in 64 registers); the kept rows are the A operand, 64 rows at a time through LDS (de-interleaved:
 // [row][kh][s], so that four steps of a lane are one 16-byte read).  64 MFMAs per 32 x 32 block of cosines = the d-ascending
 // fp32 chain (each MFMA adds its two products in k order; products of two 16-bit values are exact in fp32), at twice the
 // rate of the scalar FMA; the first maximum over the kept rows is taken with an explicit (value, smaller row) rule.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MP_STAGE = 64;                               // kept rows per LDS stage: 33 KB, four workgroups per CU
 constexpr int MP_PITCH = 132;                              // floats per kept row in LDS (16-byte reads of a quarter wave: all banks)
 template <int DT>
 __global__ __launch_bounds__(256) void merge_pivot_kernel(const MergeArgs a) {
     typedef typename Dt<DT>::raw raw;
-    extern __shared__ __attribute__((aligned(16))) float kept[];                            // [128][MP_PITCH]
+    extern __shared__ __attribute__((aligned(16))) float kept[];                            // [MP_STAGE][MP_PITCH]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kh = lane >> 5, j = lane & 31;
     const int64_t hb = blockIdx.y;
     const int b = (int)(hb / a.n_q_heads), h = (int)(hb % a.n_q_heads);
@@ -160,10 +161,10 @@ __global__ __launch_bounds__(256) void merge_pivot_kernel(const MergeArgs a) {
     float bestv = 0.0f;
     int best = 0x7fffffff;
     const float* kn = a.kn + hb * a.rows * 128;
-    for (int r0 = 0; r0 < a.rows; r0 += 128) {
-        const int nr = a.rows - r0 < 128 ? a.rows - r0 : 128;
+    for (int r0 = 0; r0 < a.rows; r0 += MP_STAGE) {
+        const int nr = a.rows - r0 < MP_STAGE ? a.rows - r0 : MP_STAGE;
         __syncthreads();
-        for (int i = tid; i < 128 * 32; i += 256) {                                         // (row, 4 consecutive d) -> evens | odds
+        for (int i = tid; i < MP_STAGE * 32; i += 256) {                                         // (row, 4 consecutive d) -> evens | odds
             const int row = i >> 5, c = i & 31;
             const float4 z = {0.0f, 0.0f, 0.0f, 0.0f};
             const float4 u = row < nr ? reinterpret_cast<const float4*>(kn + (int64_t)(r0 + row) * 128)[c] : z;
@@ -199,44 +200,57 @@ __global__ __launch_bounds__(256) void merge_pivot_kernel(const MergeArgs a) {
     if (live && kh == 0) a.pivot[hb * a.q_len + p] = best;
 }
 
-// grid = (R, bsz * H_q, 2 {K, V}), block = 64: one kept row; lane l holds elements 2l, 2l + 1
+// grid = (R, bsz * H_q), block = 64: kept row r of the KEY order and kept row r of the VALUE order (the same pivots feed both,
+// :155-160); lane l holds elements 2l, 2l + 1 of each
 template <int DT>
 __global__ __launch_bounds__(64) void merge_reduce_kernel(const MergeArgs a) {
     typedef typename Dt<DT>::raw raw;
     const int r = blockIdx.x, lane = threadIdx.x;
-    const bool is_v = blockIdx.z != 0;
     const int64_t hb = blockIdx.y;
     const int b = (int)(hb / a.n_q_heads), h = (int)(hb % a.n_q_heads);
-    const int64_t sb = is_v ? a.v_stride_b : a.k_stride_b, sh = is_v ? a.v_stride_h : a.k_stride_h, sl = is_v ? a.v_stride_l : a.k_stride_l;
-    const raw* base = reinterpret_cast<const raw*>(is_v ? a.v : a.k) + (int64_t)b * sb + (int64_t)(h / a.group) * sh;
-    const uint32_t ws = reinterpret_cast<const uint32_t*>(base + kept_pos(a, hb, r, is_v) * sl)[lane];
-    const float self0 = Dt<DT>::ld((raw)(ws & 0xffffu)), self1 = Dt<DT>::ld((raw)(ws >> 16));
-    float sum0 = self0, sum1 = self1;
+    const raw* kbase = reinterpret_cast<const raw*>(a.k) + (int64_t)b * a.k_stride_b + (int64_t)(h / a.group) * a.k_stride_h;
+    const raw* vbase = reinterpret_cast<const raw*>(a.v) + (int64_t)b * a.v_stride_b + (int64_t)(h / a.group) * a.v_stride_h;
+    const uint32_t wk = reinterpret_cast<const uint32_t*>(kbase + kept_pos(a, hb, r, false) * a.k_stride_l)[lane];
+    const uint32_t wv = reinterpret_cast<const uint32_t*>(vbase + kept_pos(a, hb, r, true) * a.v_stride_l)[lane];
+    const float ks0 = Dt<DT>::ld((raw)(wk & 0xffffu)), ks1 = Dt<DT>::ld((raw)(wk >> 16));
+    const float vs0 = Dt<DT>::ld((raw)(wv & 0xffffu)), vs1 = Dt<DT>::ld((raw)(wv >> 16));
+    float ksum0 = ks0, ksum1 = ks1, vsum0 = vs0, vsum1 = vs1;
     int cnt = 1;
     const int M = a.drop_len[b];
     const int32_t* pv = a.pivot + hb * a.q_len;
     const int32_t* drop = a.drop + (int64_t)b * a.q_len;
-    for (int p0 = 0; p0 < M; p0 += 64) {
-        const int p = p0 + lane;
-        const bool hit = p < M && pv[p] == r;
-        const int pos = hit ? drop[p] : 0;
-        unsigned long long m = __ballot(hit);
-        while (m) {
-            const int i = __builtin_ctzll(m);
-            m &= m - 1;
-            const int64_t src = __builtin_amdgcn_readlane(pos, i);
-            const uint32_t w = reinterpret_cast<const uint32_t*>(base + src * sl)[lane];
-            const float d0 = Dt<DT>::ld((raw)(w & 0xffffu)), d1 = Dt<DT>::ld((raw)(w >> 16));
-            sum0 = sum0 + rnd<DT>(rnd<DT>(d0 + self0) / 2.0f);
-            sum1 = sum1 + rnd<DT>(rnd<DT>(d1 + self1) / 2.0f);
-            ++cnt;
+    constexpr int UW = 8;                                                // chunks of 64 pivots requested together (the walk is a
+    for (int p0 = 0; p0 < M; p0 += 64 * UW) {                            // chain of L2 round trips otherwise)
+        int pvv[UW], posv[UW];
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+            const int p = p0 + u * 64 + lane;
+            pvv[u] = p < M ? pv[p] : -1;
+            posv[u] = p < M ? drop[p] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+            unsigned long long m = __ballot(pvv[u] == r);
+            while (m) {
+                const int i = __builtin_ctzll(m);
+                m &= m - 1;
+                const int64_t src = __builtin_amdgcn_readlane(posv[u], i);
+                const uint32_t dk = reinterpret_cast<const uint32_t*>(kbase + src * a.k_stride_l)[lane];
+                const uint32_t dv = reinterpret_cast<const uint32_t*>(vbase + src * a.v_stride_l)[lane];
+                ksum0 = ksum0 + rnd<DT>(rnd<DT>(Dt<DT>::ld((raw)(dk & 0xffffu)) + ks0) / 2.0f);
+                ksum1 = ksum1 + rnd<DT>(rnd<DT>(Dt<DT>::ld((raw)(dk >> 16)) + ks1) / 2.0f);
+                vsum0 = vsum0 + rnd<DT>(rnd<DT>(Dt<DT>::ld((raw)(dv & 0xffffu)) + vs0) / 2.0f);
+                vsum1 = vsum1 + rnd<DT>(rnd<DT>(Dt<DT>::ld((raw)(dv >> 16)) + vs1) / 2.0f);
+                ++cnt;
+            }
         }
     }
     const float c = rnd<DT>((float)cnt);
-    const raw o0 = Dt<DT>::st(rnd<DT>(sum0) / c), o1 = Dt<DT>::st(rnd<DT>(sum1) / c);
     const int64_t head_elems = a.out_stride_h ? a.out_stride_h : (int64_t)a.rows * 128;
-    raw* out = reinterpret_cast<raw*>(is_v ? a.v_out : a.k_out) + hb * head_elems + (int64_t)r * 128;
-    reinterpret_cast<uint32_t*>(out)[lane] = (uint32_t)o0 | ((uint32_t)o1 << 16);
+    raw* ko = reinterpret_cast<raw*>(a.k_out) + hb * head_elems + (int64_t)r * 128;
+    raw* vo = reinterpret_cast<raw*>(a.v_out) + hb * head_elems + (int64_t)r * 128;
+    reinterpret_cast<uint32_t*>(ko)[lane] = (uint32_t)Dt<DT>::st(rnd<DT>(ksum0) / c) | ((uint32_t)Dt<DT>::st(rnd<DT>(ksum1) / c) << 16);
+    reinterpret_cast<uint32_t*>(vo)[lane] = (uint32_t)Dt<DT>::st(rnd<DT>(vsum0) / c) | ((uint32_t)Dt<DT>::st(rnd<DT>(vsum1) / c) << 16);
 }
 
 template <int DT>
@@ -248,10 +262,10 @@ static int launch_merge_t(const MergeArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(merge_drop_kernel, dim3((unsigned)a.bsz), dim3(1024), 0, st, a);
     hipLaunchKernelGGL((merge_kept_kernel<DT>), dim3((unsigned)a.rows, (unsigned)heads), dim3(64), 0, st, a);
     static LdsCache lds_cache = {};
-    const size_t lds = (size_t)128 * MP_PITCH * sizeof(float);
+    const size_t lds = (size_t)MP_STAGE * MP_PITCH * sizeof(float);
     if (ensure_lds(reinterpret_cast<const void*>(&merge_pivot_kernel<DT>), lds, lds_cache) != 0) return KVC_ERR_HIP;
     hipLaunchKernelGGL((merge_pivot_kernel<DT>), dim3((unsigned)((a.q_len + 127) / 128), (unsigned)heads), dim3(256), lds, st, a);
-    hipLaunchKernelGGL((merge_reduce_kernel<DT>), dim3((unsigned)a.rows, (unsigned)heads, 2), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((merge_reduce_kernel<DT>), dim3((unsigned)a.rows, (unsigned)heads), dim3(64), 0, st, a);
     return 0;
 }
 
