@@ -100,7 +100,9 @@ typedef struct kvc_params {
                                   and reuse what the previous identical call left in the workspace and the outputs.  Bit7
                                   (H2O exact mode, testing): hold 512 query rows of the logit matrix at a time instead of
                                   as many as fit in 1 GiB (identical results).  Bit8 (measurement): the softmax stage reloads the
-                                  logits in its second pass instead of keeping the exponentials in registers (identical results). */
+                                  logits in its second pass instead of keeping the exponentials in registers (identical results).
+                                  Bit9 (measurement): G * W == 128 query rows per KV head scanned by the one-M-tile-at-a-time
+                                  kernel instead of the four-waves-share-a-tile one (identical results). */
     int32_t dot_mode;          /* kvc_dot_mode */
     int64_t q_stride_b, q_stride_h, q_stride_l;   /* element strides of q[b][h][l][:] */
     int64_t k_stride_b, k_stride_h, k_stride_l;

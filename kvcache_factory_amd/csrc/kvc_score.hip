@@ -509,6 +509,353 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
 }
 
 // ---------------------------------------------------------------------------------------------
+// logits_mt4_kernel: the same scan for G * W == 128 query rows per KV head (W = 32 with four query heads per KV head: the
+// library's default window, the needle runner's).  logits_kernel walks the keys once per 32-row M-tile — at four M-tiles the
+// PMC counters showed every K byte fetched four times (profiles/r02_pmc_batch_c2_w32_FETCH_SIZE.csv: 2.08 GB per launch for
+// 526 MB of keys).  Here the four waves of a workgroup ARE the four M-tiles: they share ONE staged K tile (loaded by all
+// 256 threads, requested two tiles ahead), each wave keeps its own Q image / packed A fragments, accumulators, running maxima
+// and epilogue.  Two barriers per tile; K is read from HBM once.  Same arithmetic, same bits.
+// ---------------------------------------------------------------------------------------------
+template <int DT, int D, int WV, bool FAST>
+__global__ __launch_bounds__(LOGITS_THREADS, 2) void logits_mt4_kernel(const ScoreArgs a) {
+    const ScoreView vw = view_of(a, blockIdx.z);
+    typedef typename Dt<DT>::raw raw;
+    constexpr int ES = Dt<DT>::esize;
+    constexpr int ROWB = D * ES;             // bytes per key row
+    constexpr bool ASM_B = (DT == KVC_BF16) && !FAST;
+    // Row pitch in LDS.  The exact bf16 scan reads ONE dword per key row per instruction (ds_read_u16_d16_hi): an odd
+    // dword pitch puts the 32 keys in 32 different banks (a 16-byte pad left 4-way conflicts: SQ_LDS_BANK_CONFLICT was
+    // 24 % of the kernel's cycles); the rows are then only 4-byte aligned and are staged with dword-pair writes.  The
+    // other variants read 16-byte chunks and keep 16-byte aligned rows.
+    constexpr int ROWP = ASM_B ? ROWB + 4 : ROWB + 16;
+    constexpr int CH = ROWB / 16;            // 16-byte chunks per row
+    constexpr int PAIRS = 8 / ES;            // mfma k-pairs per chunk: 4 (16-bit) or 2 (fp32)
+    constexpr int STG = (32 * CH) / LOGITS_THREADS > 0 ? (32 * CH) / LOGITS_THREADS : 1;   // staging registers (uint4) per THREAD per tile
+    constexpr int RPI = LOGITS_THREADS / CH; // key rows covered by one staging step of the workgroup
+    constexpr int ICH = D / 8;               // 16-byte chunks of one lane's fp32 A fragment (D/2 values)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: [4 Q images (one per wave = per M-tile): ICH chunks x 64 lanes x 16 B] [ONE tile of 32 keys x ROWP, shared]
+    constexpr int IMG_BYTES = FAST ? 0 : 64 * ICH * 16;  // the FAST scan keeps its packed A fragments in registers
+    constexpr int NSTEP = FAST ? D / 16 : ICH;            // MFMA steps per tile: D/16 (packed 16-deep) or one per A chunk
+    char* const buf = smem + LOGITS_WAVES * IMG_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: tile indices and bases stay in SGPRs
+    const uint32_t psel = lane_sel<DT>(kh);
+    const int b = blockIdx.y / a.n_kv_heads, g = blockIdx.y % a.n_kv_heads;
+    const int L = a.q_len, W = WV > 0 ? WV : a.window, G = a.group;
+    const int rows = G * W;                   // query rows sharing this KV head
+    const int n_t = (L + 31) / 32;            // 32-key tiles of this head
+    const int mt = wave;                      // this wave's M-tile: query rows 32 * wave .. + 31 (rows == 128)
+    char* const img = smem + wave * IMG_BYTES;
+    const float sqrt_d = a.sqrt_d;
+    KVC_STAMP(0);
+
+    const char* const kbase = reinterpret_cast<const char*>(vw.k) +
+                              ((int64_t)b * a.k_stride_b + (int64_t)g * a.k_stride_h) * ES;
+    const int64_t tile_bytes = (int64_t)32 * a.k_stride_l * ES;    // one tile further along the key axis
+    uint32_t koff[STG];                                            // this lane's chunks inside a tile (global side)
+#pragma unroll
+    for (int it = 0; it < STG; ++it) {
+        const int c = it * LOGITS_THREADS + tid;
+        koff[it] = (uint32_t)((c / CH) * (a.k_stride_l * ES) + (c % CH) * 16);
+    }
+    auto issue = [&](int tile, uint4 (&st)[STG]) {
+        const char* const tb = kbase + tile * tile_bytes;          // uniform
+        if (tile * 32 + 32 <= L) {
+#pragma unroll
+            for (int it = 0; it < STG; ++it) st[it] = *reinterpret_cast<const uint4*>(tb + koff[it]);
+        } else {
+#pragma unroll
+            for (int it = 0; it < STG; ++it) {
+                const int key = tile * 32 + it * RPI + tid / CH;
+                st[it] = key < L ? *reinterpret_cast<const uint4*>(tb + koff[it]) : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    char* const cdst = buf + (tid / CH) * ROWP + (tid % CH) * 16;     // LDS side of the same chunks
+    auto commit = [&](const uint4 (&st)[STG]) {
+#pragma unroll
+        for (int it = 0; it < STG; ++it) {
+            if constexpr (ASM_B) {
+                uint32_t* d = reinterpret_cast<uint32_t*>(cdst + it * (RPI * ROWP));
+                d[0] = st[it].x; d[1] = st[it].y; d[2] = st[it].z; d[3] = st[it].w;
+            } else {
+                *reinterpret_cast<uint4*>(cdst + it * (RPI * ROWP)) = st[it];
+            }
+        }
+    };
+
+    {
+        // ---- A operand: every wave converts the 32 query rows of ITS M-tile ONCE into an fp32 image in LDS, laid
+        // out as the MFMA A-fragment of every lane (lane = row + 32*parity, value s = Q[row][2s + parity]), chunk-major
+        // ([chunk][lane][4 values]) so that the waves read chunk c at one per-lane address + c*1024.
+        uint4 st[STG], st2[STG];                           // the next tile and the one after (two tiles ahead: a workgroup has
+        int tile = blockIdx.x;                             // one tile in LDS, and a tile's MFMAs last about one memory latency)
+        const int stride_t = gridDim.x;
+        if (tile < n_t) issue(tile, st);
+        if (tile + stride_t < n_t) issue(tile + stride_t, st2);
+        uint4 aq[FAST ? NSTEP : 1];                        // FAST: this lane's packed A fragments, chunk 2*s + kh of its row
+        if constexpr (FAST) {
+            const int i = mt * 32 + j;
+            const bool valid = i < rows;
+            const int hq = g * G + (valid ? i / W : 0), w = valid ? i % W : 0;
+            const char* qrow = reinterpret_cast<const char*>(vw.q) +
+                ((int64_t)b * a.q_stride_b + (int64_t)hq * a.q_stride_h + (int64_t)(L - W + w) * a.q_stride_l) * ES;
+#pragma unroll
+            for (int sI = 0; sI < NSTEP; ++sI)
+                aq[sI] = valid ? *reinterpret_cast<const uint4*>(qrow + (2 * sI + kh) * 16) : make_uint4(0, 0, 0, 0);
+        }
+        if constexpr (!FAST) {
+            constexpr int PER_ROW = ROWB / 16;             // 16-byte pieces of one query row
+            for (int pc = lane; pc < 32 * PER_ROW; pc += 64) {
+                const int r = pc / PER_ROW, cc = pc % PER_ROW;
+                const int i = mt * 32 + r;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (i < rows) {
+                    const int hq = g * G + i / W, w = i % W;
+                    const char* qrow = reinterpret_cast<const char*>(vw.q) +
+                        ((int64_t)b * a.q_stride_b + (int64_t)hq * a.q_stride_h + (int64_t)(L - W + w) * a.q_stride_l) * ES;
+                    v = *reinterpret_cast<const uint4*>(qrow + cc * 16);
+                }
+                // this piece holds pairs s = cc*PAIRS .. cc*PAIRS+PAIRS-1; element s of lane-row l sits in chunk s/4
+#pragma unroll
+                for (int sp = 0; sp < PAIRS; ++sp) {
+                    const int sidx = cc * PAIRS + sp;
+                    const int chunk = sidx >> 2, e = sidx & 3;
+                    *reinterpret_cast<float*>(img + chunk * 1024 + r * 16 + e * 4) = pick<DT>(v, sp, lane_sel<DT>(0));
+                    *reinterpret_cast<float*>(img + chunk * 1024 + (32 + r) * 16 + e * 4) = pick<DT>(v, sp, lane_sel<DT>(1));
+                }
+            }
+        }
+        if (tile < n_t) commit(st);
+        __syncthreads();                                   // images and the first tile are in place
+        KVC_STAMP(1);
+        float rm[16];                          // running maximum per accumulator register (row 8*(e/4) + 4*kh + e%4)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rm[e] = -__builtin_inff();
+        const char* const krow = buf + j * ROWP;
+        const char* const arow = img + lane * 16;
+        const uint32_t krow_a = lds_addr(krow) + 2 * kh, arow_a = lds_addr(arow);
+        // logits of this lane: element (rg, e) of key `key` goes to lg + soff[rg] + key*W*ES (+ e*ES)
+        char* const lg = reinterpret_cast<char*>(vw.logits);
+        uint32_t soff[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int i0 = mt * 32 + 8 * rg + 4 * kh;
+            const int hq = g * G + (i0 < rows ? i0 / W : 0), w0 = i0 % W;
+            soff[rg] = (uint32_t)(((((int64_t)b * a.n_q_heads + hq) * L) * W + w0) * ES);
+        }
+
+        // One epilogue element: the reference's three roundings (+ the local causal mask on the last W keys).
+        auto finish = [&](float accv, int i, int key, bool tail) -> float {
+            float v = rnd<DT>(accv);
+            v = rnd<DT>(ScaleDiv<D>::apply(v, sqrt_d));
+            if (tail) {
+                const int w = i % W;
+                if (key >= L - W && (key - (L - W)) > w) v = rnd<DT>(v + Dt<DT>::finfo_min());
+            }
+            return v;
+        };
+        // Store 4 consecutive rows (one accumulator register group) of one key: 8 bytes (16-bit) or 16 bytes (fp32).
+        auto store4 = [&](const float (&x)[4], int i0, int key) {
+            const int hq = g * G + i0 / W, w0 = i0 % W;
+            raw* dst = reinterpret_cast<raw*>(vw.logits) + (((int64_t)b * a.n_q_heads + hq) * L + key) * W + w0;
+            if constexpr (ES == 2) {
+                uint2 pk;
+                pk.x = (uint32_t)Dt<DT>::st(x[0]) | ((uint32_t)Dt<DT>::st(x[1]) << 16);
+                pk.y = (uint32_t)Dt<DT>::st(x[2]) | ((uint32_t)Dt<DT>::st(x[3]) << 16);
+                *reinterpret_cast<uint2*>(dst) = pk;
+            } else {
+                *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
+            }
+        };
+        // per-row maximum over the 32 key lanes: reduce-scatter over the 5 key bits (16 cross-lane moves): after the
+        // step on lane bit t each lane keeps only the registers whose index bit matches its own.
+        auto fold_max = [&](const float (&xs)[16]) -> float {
+            const bool b4 = (j & 16) != 0, b3 = (j & 8) != 0, b2 = (j & 4) != 0, b1 = (j & 2) != 0;
+            float y[8], z[4], u[2];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float o = xor_lane<16>(b4 ? xs[r] : xs[r + 8]);
+                const float keep = b4 ? xs[r + 8] : xs[r];
+                y[r] = o > keep ? o : keep;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float o = xor_lane<8>(b3 ? y[r] : y[r + 4]);
+                const float keep = b3 ? y[r + 4] : y[r];
+                z[r] = o > keep ? o : keep;
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float o = xor_lane<4>(b2 ? z[r] : z[r + 2]);
+                const float keep = b2 ? z[r + 2] : z[r];
+                u[r] = o > keep ? o : keep;
+            }
+            float m = xor_lane<2>(b1 ? u[0] : u[1]);
+            { const float keep = b1 ? u[1] : u[0]; m = m > keep ? m : keep; }
+            { const float o = xor_lane<1>(m); m = o > m ? o : m; }
+            return m;
+        };
+        // General epilogue (ragged tile, masked tail, padded rows, W % 4 != 0): straight after its own MFMAs.
+        auto epilogue_general = [&](const f32x16& acc, int t) {
+            const int key = t * 32 + j;
+            const bool tail = t * 32 + 32 > L - W;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float x[4];
+                const int i0 = mt * 32 + 8 * rg + 4 * kh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x[e] = finish(acc[rg * 4 + e], i0 + e, key, tail);
+                    const float xv = (key < L) ? x[e] : -__builtin_inff();
+                    rm[rg * 4 + e] = xv > rm[rg * 4 + e] ? xv : rm[rg * 4 + e];
+                }
+                if (i0 < rows && key < L) {
+                    if ((W % 4) == 0) {
+                        store4(x, i0, key);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int i = i0 + e;
+                            if (i < rows) {
+                                const int hq = g * G + i / W, w = i % W;
+                                reinterpret_cast<raw*>(vw.logits)[(((int64_t)b * a.n_q_heads + hq) * L + key) * W + w] = Dt<DT>::st(x[e]);
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        // A tile is "plain" when none of those cases applies: its epilogue is then branch-free, a pair of accumulator
+        // elements at a time on the packed-fp32 ALU.  (Riding it between the MFMA steps of the next tile, as earlier
+        // versions did, buys nothing: the f32 MFMA and the VALU do not overlap on gfx950.)
+        const bool rows_plain = (W % 4) == 0 && (mt + 1) * 32 <= rows;
+        // Plain epilogue of accumulator elements e0, e0+1 (rows i0+e0%4, +1 of register group e0/4).
+        uint32_t pkw[2];                                       // packed words of the current register group
+        auto plain_pair = [&](const f32x16& pend, int e0, uint32_t pkeyoff) {     // pend: the tile's accumulators
+            if constexpr (DT == KVC_FP32) {
+                const float v0 = ScaleDiv<D>::apply_in_guard(pend[e0], sqrt_d), v1 = ScaleDiv<D>::apply_in_guard(pend[e0 + 1], sqrt_d);
+                rm[e0] = v0 > rm[e0] ? v0 : rm[e0];
+                rm[e0 + 1] = v1 > rm[e0 + 1] ? v1 : rm[e0 + 1];
+                *reinterpret_cast<float2*>(lg + (soff[e0 >> 2] + pkeyoff + (e0 & 3) * 4)) = make_float2(v0, v1);
+            } else {
+                f32x2 x = {pend[e0], pend[e0 + 1]}, back;
+                (void)pack2<DT>(x, back);                                         // first rounding
+                const f32x2 q = scale2_in_guard<D>(back, sqrt_d);                 // second: after the scaling
+                // (maximum before rounding: monotonic.)  One v_max_f32 each, spelled out: fmaxf() makes the compiler
+                // re-canonicalise all 16 running maxima at the top of every tile
+                asm("v_max_f32 %0, %1, %2" : "=v"(rm[e0]) : "v"(rm[e0]), "v"(q.x));
+                asm("v_max_f32 %0, %1, %2" : "=v"(rm[e0 + 1]) : "v"(rm[e0 + 1]), "v"(q.y));
+                f32x2 unused;
+                pkw[(e0 >> 1) & 1] = pack2<DT>(q, unused);
+                if ((e0 & 3) == 2) *reinterpret_cast<uint2*>(lg + (soff[e0 >> 2] + pkeyoff)) = make_uint2(pkw[0], pkw[1]);
+            }
+        };
+        for (; tile < n_t; tile += stride_t) {
+            const int next = tile + stride_t, next2 = tile + 2 * stride_t;
+#pragma unroll
+            for (int it = 0; it < STG; ++it) st[it] = st2[it];  // the tile requested one iteration ago
+            if (next2 < n_t) issue(next2, st2);                // in flight during the MFMAs of this tile and the next
+            __builtin_amdgcn_wave_barrier();
+            KVC_STAMP(2);
+            // ---- 32 rows x 32 keys, chain over d = 0..D-1 in order ----
+            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            auto chain = [&]() {
+                if constexpr (ASM_B) {
+                    // operands by hand-issued LDS reads, one step ahead of the MFMAs that consume them:
+                    //   A: 4 fragment values (ds_read_b128, chunk-major image);  B: 4 x bf16 -> fp32 in the load itself.
+                    asm volatile("" ::: "memory");            // this tile's ds_writes (commit) stay above the reads
+                    f32x4 A0, A1;
+                    uint32_t B0[4], B1[4];
+                    ld_step<0>(A0, B0, arow_a, krow_a);
+                    static_for<0, NSTEP>([&](auto ic_) {
+                        constexpr int ic = decltype(ic_)::value;
+                        f32x4& Ac = (ic & 1) ? A1 : A0;
+                        uint32_t (&Bc)[4] = (ic & 1) ? B1 : B0;
+                        if constexpr (ic + 1 < NSTEP) {
+                            ld_step<ic + 1>((ic & 1) ? A0 : A1, (ic & 1) ? B0 : B1, arow_a, krow_a);
+                            wait_step<5>(Ac, Bc);             // all but the 5 reads just issued have landed
+                        } else {
+                            wait_step<0>(Ac, Bc);
+                        }
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[s4], u2f(Bc[s4]), acc, 0, 0, 0);
+                    });
+                    asm volatile("" ::: "memory");            // ... and the next tile's ds_writes stay below them
+                } else {
+                    static_for<0, NSTEP>([&](auto ic_) {
+                        constexpr int sti = decltype(ic_)::value;
+                        if constexpr (FAST) {
+                            const uint4 kv = *reinterpret_cast<const uint4*>(krow + (2 * sti + kh) * 16);
+                            acc = mfma16<DT>(aq[sti], kv, acc);
+                        } else {                               // one A chunk = 4 fragment values = 4 exact f32 MFMAs
+                            const float4 av = *reinterpret_cast<const float4*>(arow + sti * 1024);
+                            const float af[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+                            for (int kc = 0; kc < 4 / PAIRS; ++kc) {   // K chunks feeding these 4 values: 1 (16-bit) or 2 (fp32)
+                                const int c = sti * (4 / PAIRS) + kc;
+                                const uint4 kv = *reinterpret_cast<const uint4*>(krow + c * 16);
+#pragma unroll
+                                for (int sp = 0; sp < PAIRS; ++sp)
+                                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc * PAIRS + sp], pick<DT>(kv, sp, psel), acc, 0, 0, 0);
+                            }
+                        }
+                    });
+                }
+            };
+            chain();
+            asm volatile("" :: "v"(acc[0]), "v"(acc[15]));
+            // every wave has its operands of this tile in registers: the next tile may overwrite the shared buffer, its
+            // ds_writes overlap the VALU work that follows
+            __syncthreads();
+            if (next < n_t) commit(st);
+            KVC_STAMP(3);
+            bool plain = rows_plain && tile * 32 + 32 <= L - W;
+            if (plain) {
+                // the branch-free scaling needs every |value| of the tile inside [2^-98, 2^126] (rounding to dtype moves a
+                // value by < 1 %, so this keeps the rounded value inside the proven [2^-100, inf) guard); a zero logit, an
+                // overflow or a NaN sends the whole tile down the general path instead
+                uint32_t amin = f2u(acc[0]) & 0x7fffffffu, amax = amin;
+#pragma unroll
+                for (int e = 1; e < 16; ++e) {
+                    const uint32_t t = f2u(acc[e]) & 0x7fffffffu;
+                    amin = t < amin ? t : amin;
+                    amax = t > amax ? t : amax;
+                }
+                plain = !__any(!(amin >= 0x0e800000u && amax <= 0x7e800000u));
+            }
+            if (plain) {                                        // branch-free epilogue, two accumulator elements at a time
+                const uint32_t keyoff = (uint32_t)(tile * 32 + j) * (uint32_t)(W * ES);
+#pragma unroll
+                for (int pr = 0; pr < 8; ++pr) plain_pair(acc, 2 * pr, keyoff);
+            } else {
+                epilogue_general(acc, tile);
+            }
+            __syncthreads();                                  // the next tile is complete
+            KVC_STAMP(5);
+        }
+        // ---- this wave's maximum per row of its M-tile -> pmax[hq][blockIdx.x][w] ----
+        {
+            float rmr[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) rmr[e] = rnd<DT>(rm[e]);  // plain tiles kept the unrounded value (monotonic)
+            const float runmax = fold_max(rmr);
+            const int R = ((j >> 1) & 1) + ((j >> 2) & 1) * 2 + ((j >> 3) & 1) * 4 + ((j >> 4) & 1) * 8;   // accumulator register
+            if ((j & 1) == 0) {
+                const int i = mt * 32 + (R & 3) + 8 * (R >> 2) + 4 * kh;
+                if (i < rows) {
+                    const int hq = g * G + i / W, w = i % W;
+                    vw.pmax[(((int64_t)b * a.n_q_heads + hq) * a.n_tiles + blockIdx.x) * W + w] = runmax;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Row maxima of one head from the tile maxima: result in LDS m[0..W).  >= 256 threads (the first 256 work).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void block_row_max(const float* pmax /*[n_tiles][W]*/, int n_tiles, int W,
@@ -1025,6 +1372,17 @@ static void launch_softmax_pool_t(const ScoreArgs& a, hipStream_t st) {
 template <int DT, int D, int WV, bool FAST>
 static void launch_logits_t(const ScoreArgs& a, hipStream_t st) {
     constexpr int ES = Dt<DT>::esize;
+    if constexpr (WV == 32) {
+        if (a.group * WV == 128 && !(a.stage_mask & 512)) {       // four M-tiles: one K tile shared by the workgroup's waves
+            constexpr bool ASMB = (DT == KVC_BF16) && !FAST;
+            const size_t lds4 = (FAST ? 0 : (size_t)LOGITS_WAVES * 64 * (D / 2) * 4) + (size_t)32 * (D * ES + (ASMB ? 4 : 16));
+            static LdsCache lds_cache4 = {};
+            (void)ensure_lds(reinterpret_cast<const void*>(&logits_mt4_kernel<DT, D, WV, FAST>), lds4, lds_cache4);
+            dim3 g4((unsigned)a.n_tiles, (unsigned)(a.bsz * a.n_kv_heads), (unsigned)a.n_items);
+            hipLaunchKernelGGL((logits_mt4_kernel<DT, D, WV, FAST>), g4, dim3(LOGITS_THREADS), lds4, st, a);
+            return;
+        }
+    }
     const size_t lds = (FAST ? 0 : (size_t)64 * (D / 2) * 4) + (size_t)LOGITS_WAVES * 32 * (D * ES + 16) + LOGITS_WAVES * 32 * sizeof(float);
     static LdsCache lds_cache = {};
     (void)ensure_lds(reinterpret_cast<const void*>(&logits_kernel<DT, D, WV, FAST>), lds, lds_cache);   // a failure surfaces as a launch error

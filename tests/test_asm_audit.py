@@ -53,6 +53,17 @@ def test_logits_kernel_asm_loads_are_clean(score_audit):
         assert stats["asm_load_blocks"] == stats["asm_wait_blocks"] == d // 8 and stats["asm_loads"] == 5 * (d // 8)
 
 
+def test_logits_mt4_kernel_asm_loads_are_clean(score_audit):
+    """The four-M-tile scan (G * W == 128: four waves share one staged K tile) uses the same hand-issued loads."""
+    ks = {k: v for k, v in score_audit.items() if "logits_mt4_kernel" in k and "ILi0E" in k and "Lb0E" in k}   # bf16 exact
+    assert len(ks) == 2, sorted(ks)
+    for name, (problems, stats) in ks.items():
+        assert not problems, (name, problems[:5])
+        d = 128 if "Li128E" in name else 64
+        assert stats["asm_load_blocks"] == stats["asm_wait_blocks"] == d // 8 and stats["asm_loads"] == 5 * (d // 8)
+        assert stats["ScratchSize"] == 0 and stats["Occupancy"] >= 2
+
+
 def test_headline_kernel_registers_and_scratch(score_audit):
     """logits_kernel<bf16, 128, W=8, exact> — the headline's K scan: 3 waves per SIMD (<= 168 VGPRs); the few bytes of
     scratch it has (a prologue spill of the Q-image loop) stay outside the tile loop."""
