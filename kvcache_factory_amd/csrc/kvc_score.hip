@@ -510,7 +510,7 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
 
 // ---------------------------------------------------------------------------------------------
 // logits_mt4_kernel: the same scan for G * W == 128 query rows per KV head (W = 32 with four query heads per KV head: the
-// library's default window, the needle runner's).  logits_kernel walks the keys once per 32-row M-tile — at four M-tiles the
+// library's default window, the needle runner's; also W = 64 with two and W = 16 with eight).  logits_kernel walks the keys once per 32-row M-tile — at four M-tiles the
 // PMC counters showed every K byte fetched four times (profiles/r02_pmc_batch_c2_w32_FETCH_SIZE.csv: 2.08 GB per launch for
 // 526 MB of keys).  Here the four waves of a workgroup ARE the four M-tiles: they share ONE staged K tile (loaded by all
 // 256 threads, requested two tiles ahead), each wave keeps its own Q image / packed A fragments, accumulators, running maxima
@@ -1372,8 +1372,9 @@ static void launch_softmax_pool_t(const ScoreArgs& a, hipStream_t st) {
 template <int DT, int D, int WV, bool FAST>
 static void launch_logits_t(const ScoreArgs& a, hipStream_t st) {
     constexpr int ES = Dt<DT>::esize;
-    if constexpr (WV == 32) {
-        if (a.group * WV == 128 && !(a.stage_mask & 512)) {       // four M-tiles: one K tile shared by the workgroup's waves
+    if constexpr (WV == 16 || WV == 32 || WV == 64) {
+        if (a.group * WV == 128 && !(a.stage_mask & 512)) {       // four M-tiles (W = 32 x 4 heads per KV head, 64 x 2, 16 x 8):
+                                                                  // one K tile shared by the workgroup's waves
             constexpr bool ASMB = (DT == KVC_BF16) && !FAST;
             const size_t lds4 = (FAST ? 0 : (size_t)LOGITS_WAVES * 64 * (D / 2) * 4) + (size_t)32 * (D * ES + (ASMB ? 4 : 16));
             static LdsCache lds_cache4 = {};
