@@ -1274,3 +1274,49 @@ def test_w32_shared_tile_scan_equals_per_mtile_scan(kvc, oracle, gpu_device, dty
     if dot_mode == "exact" and L <= 1000:
         sc_o = oracle.scores(q, k, W, 7, "maxpool", dot_mode=oracle.DOT_CHAIN, sum_mode=oracle.SUM_TORCH16)
         assert torch.equal(G.bits(a[0].cpu()), G.bits(sc_o))
+
+
+def _random_n4_cases(n_cases, seed):
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))        # noqa: E731
+    out = []
+    for _ in range(n_cases):
+        W = (4, 8, 16, 32)[ri(0, 3)]
+        L = ri(W + 40, 900)
+        hkv, grp = (1, 2, 4)[ri(0, 2)], (1, 2, 4)[ri(0, 2)]
+        out.append((hkv, grp, W, L, (torch.bfloat16, torch.float16)[ri(0, 1)], ri(1, min(L - W, 300)), ri(0, 2)))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _random_n4_cases(18, 4040), ids=lambda c: "kv%d_g%d_W%d_L%d_%s_keep%d_c%d" % (
+    c[0], c[1], c[2], c[3], str(c[4]).split(".")[-1], c[5], c[6]))
+def test_random_shapes_n4_vs_oracle(kvc, oracle, gpu_device, case):
+    """Seeded sweep for SURVEY 8f N4 (head_dim 128): on the indices of an exact-tie SnapKV selection, kvc_merge_pivot (pivots and
+    merged K' / V'), kvc_think_prune on the compressed keys (channel scores, mask, pruned keys) and kvc_l2norm_compress (norms,
+    order, K' / V') equal the oracle bit for bit.  The keys are coarsened in a third of the cases (ties everywhere)."""
+    hkv, grp, W, L, dtype, keep, coarse = case
+    hq = hkv * grp
+    q, k, v = G.synth.make_qkv(hq, hkv, L, 128, dtype, 9100 + L + keep)
+    if coarse == 0:
+        k = (k.float() * 2).round().div(2).to(dtype)
+    qd, kd, vd = q.to(gpu_device), k.to(gpu_device), v.to(gpu_device)
+    kc, vc, idx = kvc.compress(kvc.SNAPKV, qd, kd, vd, W, keep, 7, "maxpool", "torch_cpu", return_indices=True)
+    ko_o, vo_o, idx_o, _ = oracle.compress(q, k, v, W, keep, 7, "maxpool", dot_mode=oracle.DOT_CHAIN, sum_mode=oracle.SUM_TORCH16,
+                                           tie_mode=oracle.TIES_TORCH)
+    assert torch.equal(idx[0].cpu(), idx_o)
+    km, vm, piv = kvc.merge_pivot(kvc.SNAPKV, kd, vd, idx, W, return_pivot=True)
+    km_o, vm_o, piv_o = oracle.merge_pivot(k, v, idx_o, W)
+    assert torch.equal(piv[0].cpu(), piv_o)
+    assert torch.equal(G.bits(km.cpu()), G.bits(km_o)) and torch.equal(G.bits(vm.cpu()), G.bits(vm_o))
+    if L >= 32:
+        recent = min(keep + W, (0, 5, 32)[coarse])
+        pr, rec, keepm, sc = kvc.think_prune(kc, qd, recent, 0.4, return_scores=True)
+        pr_o, rec_o, keep_o, sc_o = oracle.think_prune(ko_o, q, recent, 0.4)
+        assert torch.equal(G.bits(sc[0].cpu()), G.bits(sc_o)) and torch.equal(keepm.cpu(), keep_o)
+        assert torch.equal(G.bits(pr.cpu()), G.bits(pr_o))
+    rows = min(L, keep + W)
+    kl, vl, il, nl = kvc.l2norm_compress(kd, vd, rows, n_q_heads=hq, return_indices=True, return_norms=True)
+    kl_o, vl_o, il_o, nl_o = oracle.l2norm(k, v, rows, hq)
+    assert torch.equal(G.bits(nl[0].cpu()), G.bits(nl_o)) and torch.equal(il[0].cpu(), il_o)
+    assert torch.equal(G.bits(kl.cpu()), G.bits(kl_o)) and torch.equal(G.bits(vl.cpu()), G.bits(vl_o))
