@@ -203,6 +203,375 @@ __device__ __forceinline__ void partial_sort_wave(const typename Dt<DT>::raw* s,
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// WaveHeapL (round 3): the same heap of up to 128 packed 32-bit nodes, rebuilt around what tools/hop_probe.hip measured
+// for a wave that is alone on its SIMD: every instruction costs >= 4.4 cycles of issue whatever its unit, a scalar
+// instruction between two vector instructions that depend on each other through a mask costs 20 more, a taken branch
+// 28, an LDS write -> read -> use 72.  WaveHeap's step (mask algebra for the stop position, LDS exchange of every node
+// inside the step, 58 instructions) ran at 570-800 cycles.  Here:
+//  * along a root-to-leaf path of a heap the keys never decrease, so "__push_heap stops at the deepest path node that
+//    does not sort before `value`" is a LOCAL rule: a path node p with key(p) <= key(value) receives its chosen child's
+//    value if key(child) <= key(value) too, and `value` itself otherwise.  No stop position, no mask arithmetic.
+//  * a lane that caches its two children (xl, xr), its chosen child (xc) and the chosen child of THAT child (xcc) can
+//    bring xl / xr / xc up to date by itself: the chosen child, if it is on the path and takes part, becomes
+//    (key(xcc) <= key(value) ? xcc : value).  Only xcc has to be fetched again: one LDS exchange per step whose result
+//    is not needed before the middle of the NEXT step.  The caches are exact copies at all times, so nodes 64..127
+//    (leaves) live in their parents' xl / xr only, and the root's next key is min(key(value), key(xc of the root)) on
+//    the scalar unit — the test of the next candidate does not wait for the vector step.
+//  * __make_heap level by level: the sift-downs of one level work on disjoint subtrees, so all of them are one step
+//    with a per-lane value (6 steps instead of 60).
+// Nodes beyond the heap's length hold SENT (largest key): a lone left child wins against it, a leaf's chosen child
+// never takes part.  (A real key of 0xffff would be a NaN score: excluded, as everywhere in the exact mode.)
+// Same moves, same array as libstdc++ (tools/heap_probe.hip: 1 024 tie-heavy rows against std::partial_sort; the
+// exact-tie tests of tests/test_gpu_parity.py against the reference's fixtures).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 key_gt_mask(uint32_t a, uint32_t b) {        // lanes with key(a) > key(b): one SDWA compare
+    u64 m;
+    asm volatile("v_cmp_gt_u32_sdwa %0, %1, %2 src0_sel:WORD_1 src1_sel:WORD_1" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+// The step's instructions are single `asm volatile` statements: their order is the schedule (the compiler still places the
+// hazard nops between them); left to itself it puts a scalar mask operation right behind the compare that feeds it.
+__device__ __forceinline__ uint32_t vsel(uint32_t a, uint32_t b, u64 mask) {                  // mask bit ? b : a, in order
+    uint32_t d;
+    asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(mask));
+    return d;
+}
+struct WaveHeapL {
+    typedef HeapNode<uint32_t> N;
+    static constexpr uint32_t SENT = 0xffffffffu;
+    uint32_t lo;                     // node `lane` (nodes 0..63)
+    uint32_t xl, xr, xc, xcc;        // children of node `lane`, the chosen one, and ITS chosen child
+    uint32_t A, R;                   // ancestors of node `lane` (all <= 31) / those at which the path to `lane` goes left
+    uint32_t c0;                     // the root's chosen child (SGPR); its key is shifted out where it is used, not here:
+                                     // a scalar instruction right behind the v_readlane that feeds it waits 20 cycles
+    uint32_t* XC;                    // LDS: XC[p] = xc of node p for p < 64, SENT for 64 <= p < 192
+    int adL, adR;                    // LDS addresses of XC[2 * lane + 1], XC[2 * lane + 2]
+    int lane, lvl;
+
+    __device__ __forceinline__ uint32_t node(int i) const {         // wave-uniform i < 128
+        if (i == 0) return N::rdlane(lo, 0);
+        const int p = (i - 1) >> 1;
+        return (i & 1) ? N::rdlane(xl, p) : N::rdlane(xr, p);
+    }
+    __device__ __forceinline__ void exchange(uint32_t ad) {          // publish xc, fetch xcc (LDS, compiler-tracked), c0
+        XC[lane] = xc;
+        asm volatile("" ::: "memory");                                // one wave, LDS in order
+        typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+        xcc = *(lds_cu32*)(uintptr_t)ad;                              // ad: an LDS address
+        c0 = N::rdlane(xc, 0);
+    }
+    __device__ __forceinline__ void refresh() {                     // xc from xl / xr; the exchange
+        uint32_t ad;
+        u64 M;
+        asm volatile("v_cmp_gt_u32_sdwa %[M], %[xr], %[xl] src0_sel:WORD_1 src1_sel:WORD_1\n\t"
+                     "s_nop 1\n\t"                                            // (hazard: see step())
+                     "v_cndmask_b32_e64 %[xc], %[xr], %[xl], %[M]\n\t"
+                     "v_cndmask_b32_e64 %[ad], %[adR], %[adL], %[M]"
+                     : [M] "=&s"(M), [xc] "=&v"(xc), [ad] "=&v"(ad) : [xl] "v"(xl), [xr] "v"(xr), [adL] "v"(adL), [adR] "v"(adR));
+        exchange(ad);
+    }
+    // The moves of one __adjust_heap + __push_heap of the wave-uniform `value` from the root (if `take`: a candidate that the
+    // root has overtaken since the ballot runs the same instructions with nobody taking part — a branch costs 25 cycles
+    // whether taken or not, and nearly every candidate is live).  Two asm blocks whose instruction order is the schedule:
+    // left to itself the compiler puts a scalar mask operation right behind the compare that feeds it (20 cycles each) and a
+    // hazard nop behind every single-instruction asm statement.  Between the blocks it places the wait for the LDS read of
+    // the previous step.  gfx950 hazard (the compiler's own rule, GCNHazardRecognizer VALUWriteSGPRVALURead): a VALU
+    // instruction that reads an SGPR / VCC written by a VALU instruction needs two other instructions in between — the
+    // order below provides them (tools/heap_probe.hip without them: wrong paths).
+    // M is made from xl / xr in every step rather than carried: the compiler moves an asm-made 64-bit mask that lives across
+    // a loop into VGPRs (and then cannot hand it to a scalar operand).
+#define KVC_HEAPL_BLOCK_A                                                                                                   \
+        asm volatile("v_cmp_gt_u32_sdwa vcc, %[xr], %[xl] src0_sel:WORD_1 src1_sel:WORD_1\n\t"   /* M: the hole at node p moves left */ \
+                     "v_cmp_gt_u32_e64 %[g], %[lo], %[vor]\n\t"             /* g: key(node) > key(value) */                 \
+                     "v_cmp_gt_u32_e64 %[c], %[xc], %[vor]\n\t"             /* c: key(chosen child) > key(value) */         \
+                     "v_and_b32_e32 %[t], vcc_lo, %[A]\n\t"                                                                 \
+                     "s_mov_b64 %[M], vcc\n\t"                                                                              \
+                     "v_mov_b32_e32 %[vv], %[value]\n\t"                                                                    \
+                     "v_cmp_eq_u32_e64 %[on], %[t], %[R]\n\t"               /* on: the sift path under M (lane 0: no ancestors) */ \
+                     "v_cndmask_b32_e64 %[inner], %[xc], %[vv], %[c]"       /* what a participating node receives */        \
+                     : [t] "=&v"(t), [M] "=&s"(M), [on] "=&s"(on), [g] "=&s"(g), [c] "=&s"(c), [vv] "=&v"(vv), [inner] "=&v"(inner) \
+                     : [xl] "v"(xl), [xr] "v"(xr), [A] "v"(A), [R] "v"(R), [lo] "v"(lo), [xc] "v"(xc), [value] "s"(value), [vor] "s"(vor) : "vcc")
+    // the moves: the chosen child is xl where M is set and xr elsewhere, so only its copy xc is selected by `upd`
+#define KVC_HEAPL_MOVES                                                                                                     \
+                     "s_andn2_b64 %[upd], %[cm], %[c]\n\t"                  /* ... whose chosen child takes part too */     \
+                     "v_cndmask_b32_e32 %[nc], %[xcc], %[vv], vcc\n\t"      /* what a participating chosen child receives */ \
+                     "v_cndmask_b32_e64 %[nc], %[xc], %[nc], %[upd]\n\t"    /* the chosen child after the step */           \
+                     "v_cndmask_b32_e64 %[xl], %[xl], %[nc], %[M]\n\t"                                                      \
+                     "v_cndmask_b32_e64 %[xr], %[nc], %[xr], %[M]\n\t"
+    template <bool PRED, int PROBE = 0>                               // (tools/heap_probe.hip times the step with parts left out)
+    __device__ __forceinline__ void step(uint32_t value, uint32_t& rootor) {       // rootor: the root's (key << 16 | 0xffff), brought up to date
+        const uint32_t vor = value | 0xffffu;
+        u64 M, on, g, c, cm, upd, Mn;
+        uint32_t vv, inner, nc, ad, t, rnew;
+        KVC_HEAPL_BLOCK_A;
+        if (PRED) {
+            asm volatile("v_cmp_gt_u32_e64 vcc, %[xcc], %[vor]\n\t"
+                         "s_or_b32 %[rnew], %[c0], 0xffff\n\t"              // (c0 comes from a v_readlane: first scalar use here, late)
+                         "s_min_u32 %[rnew], %[rnew], %[vor]\n\t"           // the root's key after the step: the smaller of value's and
+                         "s_cmp_gt_u32 %[value], %[rootor]\n\t"             // its chosen child's — if the candidate is still live
+                         "s_cselect_b32 %[rnew], %[rnew], %[rootor]\n\t"
+                         "s_cselect_b64 %[cm], %[on], 0\n\t"
+                         "s_andn2_b64 %[cm], %[cm], %[g]\n\t"               // path nodes that take part
+                         KVC_HEAPL_MOVES
+                         "v_cmp_gt_u32_sdwa %[Mn], %[xr], %[xl] src0_sel:WORD_1 src1_sel:WORD_1\n\t"
+                         "v_cndmask_b32_e64 %[lo], %[lo], %[inner], %[cm]\n\t"
+                         "s_nop 0\n\t"
+                         "v_cndmask_b32_e64 %[xc], %[xr], %[xl], %[Mn]\n\t"
+                         "v_cndmask_b32_e64 %[ad], %[adR], %[adL], %[Mn]"
+                         : [nc] "=&v"(nc), [cm] "=&s"(cm), [upd] "=&s"(upd), [lo] "+v"(lo), [xl] "+v"(xl), [xr] "+v"(xr), [Mn] "=&s"(Mn),
+                           [xc] "+v"(xc), [ad] "=&v"(ad), [rnew] "=&s"(rnew)
+                         : [xcc] "v"(xcc), [vor] "s"(vor), [vv] "v"(vv), [g] "s"(g), [c] "s"(c), [inner] "v"(inner), [adL] "v"(adL), [adR] "v"(adR),
+                           [M] "s"(M), [on] "s"(on), [value] "s"(value), [rootor] "s"(rootor), [c0] "s"(c0)
+                         : "vcc", "scc");
+            rootor = rnew;
+        } else {
+            asm volatile("v_cmp_gt_u32_e64 vcc, %[xcc], %[vor]\n\t"
+                         "s_andn2_b64 %[cm], %[on], %[g]\n\t"               // path nodes that take part
+                         KVC_HEAPL_MOVES
+                         "v_cmp_gt_u32_sdwa %[Mn], %[xr], %[xl] src0_sel:WORD_1 src1_sel:WORD_1\n\t"
+                         "v_cndmask_b32_e64 %[lo], %[lo], %[inner], %[cm]\n\t"
+                         "s_nop 0\n\t"
+                         "v_cndmask_b32_e64 %[xc], %[xr], %[xl], %[Mn]\n\t"
+                         "v_cndmask_b32_e64 %[ad], %[adR], %[adL], %[Mn]"
+                         : [nc] "=&v"(nc), [cm] "=&s"(cm), [upd] "=&s"(upd), [lo] "+v"(lo), [xl] "+v"(xl), [xr] "+v"(xr), [Mn] "=&s"(Mn),
+                           [xc] "+v"(xc), [ad] "=&v"(ad)
+                         : [xcc] "v"(xcc), [vor] "s"(vor), [vv] "v"(vv), [g] "s"(g), [c] "s"(c), [inner] "v"(inner), [adL] "v"(adL), [adR] "v"(adR),
+                           [M] "s"(M), [on] "s"(on)
+                         : "vcc", "scc");
+        }
+        if (PROBE == 0) exchange(ad);
+        else if (PROBE == 1) { XC[lane] = xc; asm volatile("" ::: "memory"); typedef __attribute__((address_space(3))) const uint32_t lds_cu32; xcc = *(lds_cu32*)(uintptr_t)ad; }
+        else if (PROBE == 2) c0 = N::rdlane(xc, 0);
+        else xcc = ad;
+    }
+    // __sort_heap's step: the same moves, with the NEXT pop's bookkeeping (read node last - 1, park the root in the result
+    // array, take the node out of its parent's cache) between the moves and the new M — one exchange per pop instead of two.
+    // `value` = the node this pop removed (already out of the caches); returns the next pop's value.  res: LDS, k words.
+    __device__ __forceinline__ uint32_t pop_step(uint32_t value, int next_last, uint32_t* res) {
+        const uint32_t vor = value | 0xffffu;
+        u64 M, on, g, c, cm, upd;
+        uint32_t vv, inner, nc, t;
+        KVC_HEAPL_BLOCK_A;
+        asm volatile("v_cmp_gt_u32_e64 vcc, %[xcc], %[vor]\n\t"
+                     "s_andn2_b64 %[cm], %[on], %[g]\n\t"
+                     KVC_HEAPL_MOVES
+                     "v_cndmask_b32_e64 %[lo], %[lo], %[inner], %[cm]"
+                     : [nc] "=&v"(nc), [cm] "=&s"(cm), [upd] "=&s"(upd), [lo] "+v"(lo), [xl] "+v"(xl), [xr] "+v"(xr)
+                     : [xcc] "v"(xcc), [vor] "s"(vor), [vv] "v"(vv), [g] "s"(g), [c] "s"(c), [inner] "v"(inner), [M] "s"(M), [on] "s"(on), [xc] "v"(xc)
+                     : "vcc", "scc");
+        // the next pop: its node is read out of the parent's cache, the root goes to res[next_last] (every lane stores the same
+        // word: no branch), SENT takes the node's place.  next_last == 0: node 0 is its own parent's ... nobody's: harmless.
+        const int p = (next_last - 1) >> 1;
+        const uint32_t nl = N::rdlane(xl, p & 63), nr = N::rdlane(xr, p & 63);
+        uint32_t top = N::rdlane(lo, 0);
+        asm volatile("" : "+v"(top));
+        res[next_last] = top;
+        const u64 pm = next_last >= 1 ? 1ull << p : 0ull;
+        xl = lane_sel(xl, SENT, (next_last & 1) ? pm : 0ull);
+        xr = lane_sel(xr, SENT, (next_last & 1) ? 0ull : pm);
+        refresh();
+        return (next_last & 1) ? nl : nr;
+    }
+#undef KVC_HEAPL_BLOCK_A
+#undef KVC_HEAPL_MOVES
+    // lo_init / hi_init: nodes lane, lane + 64 (SENT beyond the length)
+    __device__ __forceinline__ void init(uint32_t* lds, uint32_t lo_init, uint32_t hi_init) {
+        lane = threadIdx.x;
+        lvl = 31 - __clz(lane + 1);
+        XC = lds;
+        {
+            typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+            const int base = (int)(uintptr_t)(lds_u32_t*)lds;
+            adL = base + 8 * lane + 4; adR = base + 8 * lane + 8;
+        }
+        A = R = 0;
+        for (int c = lane; c > 0;) { const int p = (c - 1) >> 1; A |= 1u << p; if (c & 1) R |= 1u << p; c = p; }
+        lo = lo_init;
+        lds[lane] = lo_init; lds[lane + 64] = hi_init; lds[lane + 128] = SENT;
+        __syncthreads();
+        xl = lds[2 * lane + 1]; xr = lds[2 * lane + 2];
+        __syncthreads();
+        lds[lane + 64] = SENT;
+        refresh();
+    }
+    // __make_heap(first, first + k): libstdc++ sifts node (k - 2) / 2 .. 0 down one after the other; the nodes of one level
+    // own disjoint subtrees, so one level is one step in which every lane works with its own subtree's value.
+    __device__ __forceinline__ void make_heap(int k) {
+        if (k < 2) return;
+        uint32_t* const LO = XC + 64;                                  // XC[64..128) is SENT between steps: restored below
+        for (int d = 31 - __clz((k - 2) / 2 + 1); d >= 0; --d) {
+            const uint32_t maskd = d >= 6 ? 0u : ~((1u << ((1 << d) - 1)) - 1u);   // nodes of level >= d
+            const int anc = lvl >= d ? ((lane + 1) >> (lvl - d)) - 1 : lane;
+            // (plain C++ selects: the compiler places the hazard nops between a compare and the select it feeds)
+            const bool left = (xr >> 16) > (xl >> 16);                 // the hole at this node moves to the LEFT child
+            const uint32_t Mlo = (uint32_t)__ballot(left);
+            LO[lane] = lo;
+            asm volatile("" ::: "memory");
+            const uint32_t v = LO[anc], vor = v | 0xffffu;
+            const bool onp = lvl >= d && ((Mlo & A & maskd) == (R & maskd));
+            const bool takes = onp && !(lo > vor), child_takes = takes && !(xc > vor);
+            const uint32_t inner = xc > vor ? v : xc, nc = xcc > vor ? v : xcc;
+            lo = takes ? inner : lo;
+            xl = (child_takes && left) ? nc : xl;
+            xr = (child_takes && !left) ? nc : xr;
+            if (d > 0) {                                               // the level above caches this level's nodes
+                asm volatile("" ::: "memory");
+                LO[lane] = lo;
+                asm volatile("" ::: "memory");
+                const uint32_t cl = LO[(2 * lane + 1) & 63], cr = LO[(2 * lane + 2) & 63];     // no divergent branch here: it
+                xl = (lvl == d - 1 && 2 * lane + 1 < 64) ? cl : xl;                             // would move M into VGPRs
+                xr = (lvl == d - 1 && 2 * lane + 2 < 64) ? cr : xr;
+            }
+            asm volatile("" ::: "memory");
+            LO[lane] = SENT;
+            refresh();
+        }
+    }
+    // node `last` leaves the heap (__sort_heap): SENT in its parent's cache (its own lane never takes part again: a parent
+    // whose children are both SENT moves right, and a chosen SENT child stops every update)
+    __device__ __forceinline__ void remove(int last) {
+        const u64 pm = 1ull << ((last - 1) >> 1);
+        if (last & 1) xl = lane_sel(xl, SENT, pm); else xr = lane_sel(xr, SENT, pm);
+    }
+};
+
+// std::partial_sort(first, first + k, last, greater-by-value) for 1 <= k <= 128, 16-bit dtypes, n <= 65536.
+#if defined(KVC_HEAP_STAMPS)        // tools/heap_probe.hip: phase stamps of one wave (never defined in the library build)
+__device__ unsigned long long g_heap_stamps[8];
+#define KVC_HSTAMP(i) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_heap_stamps[i] = t_; } while (0)
+#else
+#define KVC_HSTAMP(i) do { } while (0)
+#endif
+// The row reaches the wave through LDS: 16-byte loads of the aligned vectors that cover it (an aligned vector that holds one
+// valid byte lies within that byte's page: the few elements before the row and beyond its end are loaded, never looked at),
+// 1 024 vectors = 8 192 keys per segment, every load of a segment in flight at once — the first one feeds the heap, the
+// others land while __make_heap runs; a later segment is requested before the scan of the one in LDS begins.  (Round 2 read
+// the tail with predicated 2-byte loads, which the compiler serialises: one memory round trip per 64 keys, 53 000 cycles of
+// a C2 head's 380 000.)  Keys are made while the vectors are written to LDS, two per operation.  The scan looks at 512 keys
+// per step first (each lane the largest of its eight, packed maxima): late in the row nearly every such batch holds nothing
+// above the root.
+constexpr int kSegKeys = 8192;
+constexpr size_t kWaveHeapLLds = (192 + 128) * 4 + (size_t)kSegKeys * 2;      // heap exchange area, one segment of keys
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t keys16x2(uint32_t x) {                     // Key<bf16 | fp16>::of on both halves
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    const s16x2 sg = __builtin_bit_cast(s16x2, x) >> (s16x2)15;                // v_pk_ashrrev_i16: 0xffff where negative
+    return x ^ ((__builtin_bit_cast(uint32_t, sg) & 0x7fff7fffu) | 0x80008000u);
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+template <int DT>
+__device__ __forceinline__ void partial_sort_waveL(const typename Dt<DT>::raw* s, int n_, int k_, uint32_t* lds, int64_t* out) {
+    static_assert(Key<DT>::bits == 16, "packed 32-bit nodes");
+    typedef HeapNode<uint32_t> N;
+    const int lane = threadIdx.x;
+    uint16_t* const seg = reinterpret_cast<uint16_t*>(lds + 320);
+    // wave-uniform by construction; said so (an item's pointer and budget come out of by-value argument tables, which the
+    // compiler may index through scratch: without this, loop bounds and the step's scalar operands would sit in VGPRs)
+    const int n = uni(n_), k = uni(k_);
+    const uintptr_t addr = (uintptr_t)uni((u64)reinterpret_cast<uintptr_t>(s));
+    const int e0 = (int)(addr & 15) >> 1;                                      // row element i = key e0 + i of the vectors
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) const u32x4 glb_vec;               // global_load, not flat_load (which would tie every LDS wait to the loads in flight)
+    glb_vec* const vec = (glb_vec*)(addr & ~(uintptr_t)15);
+    const int total = e0 + n, nvec = (total + 7) >> 3;
+    constexpr int VPL = kSegKeys / 8 / 64;                                      // vectors per lane and segment: 16
+    u32x4 r[VPL];
+    auto request = [&](int g) {
+#pragma unroll
+        for (int u = 0; u < VPL; ++u) { int v = g * (kSegKeys / 8) + u * 64 + lane; v = v < nvec ? v : nvec - 1; r[u] = vec[v]; }
+    };
+    auto land = [&](int u) {
+        u32x4 x = r[u];
+        x.x = keys16x2(x.x); x.y = keys16x2(x.y); x.z = keys16x2(x.z); x.w = keys16x2(x.w);
+        reinterpret_cast<u32x4*>(seg)[u * 64 + lane] = x;
+    };
+    request(0);
+    KVC_HSTAMP(0);
+    land(0);                                                                    // keys 0 .. 511 - e0: the heap's k <= 128
+    __syncthreads();
+    WaveHeapL H;
+    H.init(lds, lane < k ? N::make(seg[e0 + lane], lane) : WaveHeapL::SENT,
+           lane + 64 < k ? N::make(seg[e0 + lane + 64], lane + 64) : WaveHeapL::SENT);
+    KVC_HSTAMP(1);
+    H.make_heap(k);
+    KVC_HSTAMP(2);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int u = 1; u < VPL; ++u) land(u);
+    // __heap_select: every later element that sorts before the root replaces it (__pop_heap + __adjust_heap)
+    uint32_t rootor = N::rdlane(H.lo, 0) | 0xffffu;                            // the root's key, as (key << 16 | 0xffff)
+    constexpr int U = 8;
+    for (int g = 0; g * kSegKeys < total; ++g) {
+        const bool more = (g + 1) * kSegKeys < total;
+        __syncthreads();
+        if (more) request(g + 1);
+        for (int jb = 0; jb < kSegKeys; jb += U * 64) {
+            const int ib = g * kSegKeys + jb - e0;                               // row element of the batch's first key
+            if (ib + U * 64 <= k || ib >= n) continue;
+            {   // can any of the 512 keys replace the root?  (keys outside [k, n) only make this test conservative)
+                const u32x4 x = reinterpret_cast<const u32x4*>(seg)[jb / 8 + lane];
+                const uint32_t rr = (rootor >> 16) | (rootor & 0xffff0000u);
+                const uint32_t mx = pk_max_u16(pk_max_u16(pk_max_u16(x.x, x.y), pk_max_u16(x.z, x.w)), rr);
+                if (__ballot(mx != rr) == 0) continue;
+            }
+            uint32_t cur[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) cur[j] = seg[jb + j * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int i0 = ib + j * 64;
+                const uint32_t nodev = (cur[j] << 16) | (uint32_t)(i0 + lane);       // the candidates as heap nodes
+                u64 pending = __ballot(nodev > rootor);
+                if (i0 < k || i0 + 64 > n) pending &= __ballot(i0 + lane >= k && i0 + lane < n);
+                if (pending) {
+                    // One branch per candidate.  The candidate after this one is read out of its lane before the step: a scalar
+                    // compare right behind the v_readlane that feeds it would wait 20 cycles.
+                    int src = __builtin_ctzll(pending);
+                    uint32_t v = __builtin_amdgcn_readlane(nodev, src);
+                    do {
+                        asm volatile("s_bitset0_b64 %0, %1" : "+s"(pending) : "s"(src));
+                        const int src2 = __builtin_ctzll(pending | (1ull << 63));      // (lane 63 when nothing is left: never used)
+                        const uint32_t v2 = __builtin_amdgcn_readlane(nodev, src2);
+                        H.template step<true>(v, rootor);                          // (re-tests v against the live root)
+                        src = src2; v = v2;
+                    } while (pending);
+                }
+            }
+        }
+        if (more) {
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < VPL; ++u) land(u);
+        }
+    }
+    KVC_HSTAMP(3);
+    // __sort_heap: the root goes to a[last], a[last] is re-inserted from the top
+    uint32_t* const res = lds + 192;
+    if (k >= 2) {
+        const int last = k - 1;
+        uint32_t value = H.node(last), top = N::rdlane(H.lo, 0);
+        asm volatile("" : "+v"(top));
+        res[last] = top;
+        H.remove(last);
+        H.refresh();
+        for (int l = last; l >= 1; --l) value = H.pop_step(value, l - 1, res);      // (the last one stores res[0])
+    } else {
+        res[0] = H.lo;                                                           // k == 1: lane 0's node; every lane writes, lane 63 last
+        asm volatile("" ::: "memory");
+        if (lane == 0) res[0] = H.lo;
+    }
+    KVC_HSTAMP(4);
+    __syncthreads();
+    if (lane < k) out[lane] = N::index(res[lane]);
+    if (lane + 64 < k) out[lane + 64] = N::index(res[lane + 64]);
+    KVC_HSTAMP(5);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // nth_element + sort regime, one wavefront: the same moves as kvc_stl_emul.h, with the two loops that dominate made
 // lane-parallel.
 //
@@ -901,16 +1270,18 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const SelectArgs a, u6
     int* stack = reinterpret_cast<int*>(smem);                        // 3 * 96 ints
     u64* lds_arr = reinterpret_cast<u64*>(smem + 1152);
     const int lane = threadIdx.x, head = blockIdx.x, item = blockIdx.y;
-    const int n = a.n, k = a.k.v[item];
-    const raw* s = reinterpret_cast<const raw*>(a.scores.p[item]) + (int64_t)head * n;
-    int64_t* out = reinterpret_cast<int64_t*>(const_cast<void*>(a.idx.p[item])) + (int64_t)head * k;
+    // wave-uniform by construction; said so: the per-item tables are by-value arguments indexed at run time, which the
+    // compiler may read through scratch — every branch below would then count as divergent
+    const int n = uni(a.n), k = uni(a.k.v[item]);
+    const raw* s = reinterpret_cast<const raw*>((uintptr_t)uni((u64)reinterpret_cast<uintptr_t>(a.scores.p[item]))) + (int64_t)head * n;
+    int64_t* out = reinterpret_cast<int64_t*>((uintptr_t)uni((u64)reinterpret_cast<uintptr_t>(a.idx.p[item]))) + (int64_t)head * k;
     const bool use_partial_sort = (int64_t)k * 64 <= (int64_t)n;
 
     // (key << 16 | index) nodes need indices below 65536; longer rows (128k contexts, AdaKV's flattened [H * n] array) take
     // the 64-bit nodes
     if (use_partial_sort && k <= kWaveHeapMaxK) {
         if (Key<DT>::bits == 16 && n <= 65536) {
-            if constexpr (Key<DT>::bits == 16) partial_sort_wave<DT, uint32_t>(s, n, k, reinterpret_cast<uint32_t*>(lds_arr), out);
+            if constexpr (Key<DT>::bits == 16) partial_sort_waveL<DT>(s, n, k, reinterpret_cast<uint32_t*>(lds_arr), out);
         } else {
             partial_sort_wave<DT, u64>(s, n, k, lds_arr, out);
         }
@@ -1081,6 +1452,9 @@ static int launch_exact_t(const SelectArgs& a, void* scratch, hipStream_t st) {
     size_t body = (in_lds && any_nth) ? (packed ? (size_t)((a.n + 1) & ~1) * 4 : (size_t)a.n * 8) : (size_t)a.k_max * 8;
     if (body < kWaveHeap9Lds) body = kWaveHeap9Lds;
     if (body < kWaveHeapLds) body = kWaveHeapLds;                   // 64-bit nodes (fp32, or n > 65536)
+    bool any_heap_l = false;                                        // WaveHeapL items: heap + one staged segment of keys
+    for (int i = 0; i < a.n_items; ++i) any_heap_l = any_heap_l || (Key<DT>::bits == 16 && a.n <= 65536 && a.k.v[i] <= kWaveHeapMaxK && (int64_t)a.k.v[i] * 64 <= (int64_t)a.n);
+    if (any_heap_l && body < kWaveHeapLLds) body = kWaveHeapLLds;
     const size_t list_bytes = any_nth ? list_region_bytes(1152 + body, a.n) : 0;
     const size_t lds = 1152 + body + list_bytes;
     if (any_nth && !scratch) return KVC_ERR_WORKSPACE;
