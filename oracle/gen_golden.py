@@ -227,6 +227,30 @@ def run_merge_case(c):
     return meta, out
 
 
+def run_all_layers_case(c):
+    """PyramidKV over EVERY layer of the model (the schedule of pyramidkv_utils.py:205-215 gives each layer its own budget, and
+    with it a different libstdc++ regime / tie-group cut): one input, n_layers reference runs.  Stored per layer: the indices
+    (uint16: L <= 65536) and SHA-256 of K' / V' and of the pooled scores."""
+    dtype = DT[c["dtype"]]
+    q, k, v = synth.make_qkv(c["Hq"], c["Hkv"], c["L"], c["D"], dtype, c["seed"], peaky=c.get("peaky", False), expanded=True)
+    meta = dict(c)
+    meta["passthrough"] = False
+    meta["layers"] = {}
+    out = {}
+    t0 = time.time()
+    for layer in range(c["n_layers"]):
+        cl = ref.PyramidKVCluster(num_hidden_layers=c["n_layers"], layer_idx=layer, window_size=c["W"], max_capacity_prompt=c["cap"],
+                                  kernel_size=c["kernel"], pooling=c["pooling"])
+        with TopkTap() as tap, contextlib.redirect_stdout(io.StringIO()):
+            ko, vo = cl.update_kv(k, q, v, None, c["Hq"] // c["Hkv"])
+        sc, val, idx = tap.calls[0]
+        assert int(idx.max()) < 65536
+        out[f"indices_L{layer}"] = idx[0].numpy().astype(np.uint16)
+        meta["layers"][str(layer)] = {"n_keep": int(idx.shape[-1]), "k_out_sha256": sha(ko), "v_out_sha256": sha(vo), "scores_sha256": sha(sc[0])}
+    meta["ref_seconds"] = round(time.time() - t0, 4)
+    return meta, out
+
+
 def make_cluster(c):
     kw = dict(window_size=c["W"], max_capacity_prompt=c["cap"], kernel_size=c["kernel"], pooling=c["pooling"])
     m = c["method"]
@@ -268,6 +292,8 @@ def run_case(c, store_scores):
         out["values"] = raw_bits(val[0])
         if store_scores:
             out["scores"] = raw_bits(sc[0])
+        for h in c.get("store_scores_of_heads", []):          # a config-size case: the pooled scores of named heads only
+            out[f"scores_head{h}"] = raw_bits(sc[0, h])
     elif c["method"] == "streamingllm" and not meta["passthrough"]:
         meta["n_keep"] = c["cap"] - c["W"]
     return meta, out
@@ -327,9 +353,13 @@ def cases():
         add(f"C4_pyramidkv_8k_layer{layer}", method="pyramidkv", L=8000, cap=128, layer_idx=layer, seed=0, **big)
     add("C3_h2o_8k_2heads", method="h2o", L=8000, cap=128, Hq=2, Hkv=1, D=128, W=8, seed=0)
     # C3 at full size (all 32 query heads over 8 KV heads; ~12 GB and ~2 min of reference time: indices + hashes only)
-    add("C3_h2o_8k", method="h2o", L=8000, cap=128, Hq=32, Hkv=8, D=128, W=8, seed=0)
+    # head 27: the one head whose GPU / oracle selection differs from the reference's (tests: C3_RESIDUAL); its scores are kept
+    add("C3_h2o_8k", method="h2o", L=8000, cap=128, Hq=32, Hkv=8, D=128, W=8, seed=0, store_scores_of_heads=[27])
     for layer in (0, 28, 31):
         add(f"C5_pyramidkv_32k_layer{layer}", method="pyramidkv", L=32000, cap=2048, layer_idx=layer, seed=0, **big)
+    # C4 / C5 with EVERY layer's budget (indices as uint16 + hashes): all 32 tie-group cuts of each config against the reference
+    add("C4_pyramidkv_8k_all_layers", method="pyramidkv_all_layers", L=8000, cap=128, seed=0, **big)
+    add("C5_pyramidkv_32k_all_layers", method="pyramidkv_all_layers", L=32000, cap=2048, seed=0, **big)
     # ---- AdaKV / HeadKV (ragged per-head budgets; window MEAN scoring) ----
     for dt in ("bf16", "fp16", "fp32"):
         add(f"adakv_{dt}_L600", method="adakv", dtype=dt, Hq=8, Hkv=2, L=600, D=128, W=8, cap=72, kernel=7, pooling="maxpool", floor=0.2, normalize=True)
@@ -390,6 +420,8 @@ def main():
             meta, arrays = run_think_case(c)
         elif c["method"].startswith("merge_"):
             meta, arrays = run_merge_case(c)
+        elif c["method"] == "pyramidkv_all_layers":
+            meta, arrays = run_all_layers_case(c)
         else:
             meta, arrays = run_case(c, store_scores=small)
         manifest[c["name"]] = meta

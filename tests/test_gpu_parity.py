@@ -134,8 +134,28 @@ def test_compress_exact_ties_equals_reference(kvc, gpu_device, name):
         assert G.sha(ko) == m["k_out_sha256"] and G.sha(vo) == m["v_out_sha256"]
 
 
+@pytest.mark.parametrize("name", G.names(lambda m: m["method"] == "pyramidkv_all_layers"))
+def test_every_layer_budget_equals_reference(kvc, gpu_device, name):
+    """C4 (8k) and C5 (Mistral 32k -> 2048) with ALL 32 layers' budgets in one kvc_compress_batch call, as the layer-batching host
+    issues them: every layer's indices (set and order) and K' / V' bytes are the reference's (round 2 pinned 4 and 3 layers)."""
+    m, arr = G.MANIFEST[name], G.arrays(name)
+    qd, kd, vd = G.inputs(m, device=gpu_device, expanded=False)
+    keeps = [m["layers"][str(l)]["n_keep"] for l in range(m["n_layers"])]
+    assert keeps == [kvc.pyramid_k(m["cap"], m["W"], m["L"], l, m["n_layers"]) for l in range(m["n_layers"])]
+    bp = kvc.BatchPlan(kvc.PYRAMIDKV, [(qd, kd, vd)] * m["n_layers"], m["W"], keeps, m["kernel"], m["pooling"], "torch_cpu", want_indices=True)
+    ko, vo = bp.run()
+    torch.cuda.synchronize()
+    for l in range(m["n_layers"]):
+        lm = m["layers"][str(l)]
+        assert torch.equal(bp.idx[l][0].cpu(), torch.from_numpy(arr[f"indices_L{l}"].astype("int64"))), l
+        assert G.sha(ko[l]) == lm["k_out_sha256"] and G.sha(vo[l]) == lm["v_out_sha256"], l
+
+
 H2O = lambda m: m["method"] == "h2o" and not m["passthrough"]      # noqa: E731
-C3_MIN_HEADS, C3_MIN_OVERLAP = 31, 0.999    # measured on MI355X: 31 of 32 heads identical in set and order, index overlap 0.9997
+# C3 at full size: 31 heads identical to the reference, and head 27 differs by exactly one index because ONE of its pooled scores
+# (key 28, never selected, but part of the initial heap) is 0x3f73 here and 0x3f72 in the reference — torch's opaque bf16 GEMM.
+# Named, not thresholded (tests/test_oracle_golden.py::test_c3_residual_is_one_score_bit_of_one_head has the whole story).
+C3_RESIDUAL = {"head": 27, "score_index": 28, "reference_bits": 0x3f72, "product_bits": 0x3f73, "product_only": [1251], "reference_only": [1700]}
 
 
 @pytest.mark.parametrize("dtype,L,W,D", [(torch.bfloat16, 1304, 8, 128), (torch.bfloat16, 1301, 8, 128), (torch.float16, 1100, 32, 64),
@@ -195,17 +215,21 @@ def test_h2o_scores_bit_exact_vs_oracle_and_reference(kvc, oracle, gpu_device, n
         assert torch.equal(G.bits(sc_g[0]), G.bits(sc_o))                   # tolerance: 0 ulp
     ko, vo, idx = kvc.compress(kvc.H2O, qd, kd, vd, m["W"], m["n_keep"], m["kernel"], None, "torch_cpu", return_indices=True)
     ref_idx = torch.from_numpy(arr["indices"])
-    heads_equal = int((idx[0].cpu() == ref_idx).all(-1).sum())
-    if m["dtype"] == "fp32":
-        assert heads_equal >= m["Hq"] - 1
-    elif m["Hq"] > 8:
-        # C3 at full size (32 heads x 8000 x 8000 probabilities): the reference's scores are column sums of 8000 bf16
-        # probabilities from torch's opaque bf16 GEMM and exp; a 1-ulp flip in a few of them moves a pooled score by one
-        # bf16 ulp and with it the cut through a tie group.  Measured (tools/c3_parity_probe.py): see C3_MIN_HEADS.
-        overlap = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(idx[0].cpu(), ref_idx)) / ref_idx.numel()
-        assert heads_equal >= C3_MIN_HEADS and overlap >= C3_MIN_OVERLAP, (heads_equal, overlap)
-    else:
-        assert heads_equal == m["Hq"]
+    if m["Hq"] > 8:
+        R = C3_RESIDUAL
+        got = idx[0].cpu()
+        bad = [h for h in range(m["Hq"]) if not torch.equal(got[h], ref_idx[h])]
+        assert bad == [R["head"]]                                           # the other 31 heads: set AND order
+        a, b = set(got[R["head"]].tolist()), set(ref_idx[R["head"]].tolist())
+        assert sorted(a - b) == R["product_only"] and sorted(b - a) == R["reference_only"]
+        ref_sc = G.from_bits(arr[f"scores_head{R['head']}"], G.DT[m["dtype"]])
+        diff = (G.bits(sc_g[0][R["head"]]) != G.bits(ref_sc)).nonzero().flatten().tolist()
+        assert diff == [R["score_index"]] and int(G.bits(sc_g[0][R["head"]])[diff[0]]) & 0xffff == R["product_bits"]
+        # the selection itself is exact: on the REFERENCE's scores of that head the device returns the reference's indices
+        on_ref = kvc.select(ref_sc.reshape(1, 1, -1).contiguous().to(gpu_device), m["n_keep"], "torch_cpu")[0, 0].cpu()
+        assert torch.equal(on_ref, ref_idx[R["head"]])
+    else:                                                                   # every other H2O fixture, fp32 included
+        assert torch.equal(idx[0].cpu(), ref_idx)
         assert G.sha(ko) == m["k_out_sha256"] and G.sha(vo) == m["v_out_sha256"]
     # canonical ties: same selected values, deterministic order
     idx_c = kvc.compress(kvc.H2O, qd, kd, vd, m["W"], m["n_keep"], m["kernel"], None, "canonical", return_indices=True)[2]
