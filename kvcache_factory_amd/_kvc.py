@@ -615,10 +615,84 @@ class BatchPlan:
         return self.k_out, self.v_out
 
 
+class GroupPlan:
+    """kvc_compress_batch for a group of layers that RECURS (the same layout and budgets for every prompt): parameter block,
+    ctypes tables and workspace size are built once; `run` writes this call's pointers into the tables and makes the one C call.
+    What a prompt pays per group on the host is then ~40 pointer reads instead of building a BatchPlan (the reference's call
+    site runs once per layer, llama_model.py:283-286; PrefillBatch.flush keeps these plans per (layout, budgets))."""
+
+    def __init__(self, method, q0, k0, v0, window, keeps, kernel_size, pooling, tie_mode, q_rows="window", n_q_heads=None,
+                 out_strides=None, dot_mode=None):
+        scoring = method != STREAMINGLLM
+        self.n = n = len(keeps)
+        self.p = make_params(method, q0 if scoring else None, k0, v0, window, max(keeps), kernel_size, pooling if scoring else None,
+                             tie_mode, dot_mode)
+        if not scoring:
+            self.p.n_q_heads = n_q_heads if n_q_heads is not None else k0.shape[1]
+        self.q_off = 0
+        if scoring and q_rows == "window":
+            assert method != H2O and q0.shape[2] == window, "q_rows='window' needs [bsz,H,W,D] queries"
+            self.q_off = (k0.shape[2] - window) * q0.stride(2) * q0.element_size()
+        arr = ctypes.c_void_p * n
+        self._keep = (ctypes.c_int32 * n)(*keeps)
+        self._q = arr() if scoring else None
+        self._k, self._v, self._ko, self._vo = arr(), arr(), arr(), arr()
+        self._strides = (ctypes.c_int64 * n)(*out_strides) if out_strides is not None else None
+        self.nbytes = lib().kvc_workspace_bytes_batch(ctypes.byref(self.p), n, self._keep)
+        if self.nbytes == 0 and scoring:
+            raise KvcError(ERR_INVALID, lib().kvc_last_error().decode())
+        self._pp = ctypes.byref(self.p)
+        self._fn = lib().kvc_compress_batch
+
+    def run(self, dev, qs, ks, vs, kbufs, vbufs):
+        """Pointers only (tensors of the plan's layout, checked by the caller's layout key); enqueues on the current stream."""
+        if self._q is not None:
+            off = self.q_off
+            self._q[:] = [t.data_ptr() - off for t in qs]
+        self._k[:] = [t.data_ptr() for t in ks]
+        self._v[:] = [t.data_ptr() for t in vs]
+        self._ko[:] = [t.data_ptr() for t in kbufs]
+        self._vo[:] = [t.data_ptr() for t in vbufs]
+        ws = workspace(dev, self.nbytes) if self.nbytes else None
+        rc = _call(dev, self._fn, self._pp, self.n, self._keep, self._q, self._k, self._v, self._ko, self._vo, None, None,
+                   self._strides, _ptr(ws), self.nbytes, _stream(dev))
+        if rc:
+            _check(rc)
+
+
+_GROUP_PLANS = {}                                        # layout key -> GroupPlan (compress_batch(reuse=True))
+
+
 def compress_batch(method, qs, ks, vs, window, keeps, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu",
-                   q_rows="all", n_q_heads=None, return_indices=False, dot_mode=None, outs=None):
+                   q_rows="all", n_q_heads=None, return_indices=False, dot_mode=None, outs=None, reuse=False):
     """n independent update_kv bodies of one layout in ONE library call (kvc_compress_batch): lists of k_out, v_out
-    (and indices).  See BatchPlan for q_rows."""
+    (and indices).  See BatchPlan for q_rows.
+    reuse=True (PrefillBatch.flush: the same group of layers comes back with every prompt): the plan of this layout and
+    these budgets is kept (GroupPlan) and only the pointers are refreshed; the caller vouches that the items share the
+    first item's shape / strides / dtype / device (it grouped them by exactly that)."""
+    if reuse and not return_indices:
+        scoring = method != STREAMINGLLM
+        q0, k0, v0 = (qs[0] if scoring else None), ks[0], vs[0]
+        _require_gpu(q0, k0, v0)
+        dev = k0.device
+        keeps = tuple(keeps)
+        hq = q0.shape[1] if scoring else (n_q_heads if n_q_heads is not None else k0.shape[1])
+        if outs is None:
+            trip = [_out_views(None, k0.shape[0], hq, kk + window, k0.shape[3], k0.dtype, dev) for kk in keeps]
+            strides = None
+        else:
+            trip = [(o[0], o[1], o[0].stride(1)) for o in outs]
+            strides = tuple(t[2] for t in trip)
+        key = (method, tuple(k0.shape), k0.stride(), v0.stride(), q0.stride() if scoring else None, k0.dtype, dev, hq, window, keeps,
+               kernel_size, pooling, tie_mode, q_rows, dot_mode, strides)
+        plan = _GROUP_PLANS.get(key)
+        if plan is None:
+            if len(_GROUP_PLANS) >= 64:
+                _GROUP_PLANS.clear()
+            plan = _GROUP_PLANS[key] = GroupPlan(method, q0, k0, v0, window, list(keeps), kernel_size, pooling, tie_mode, q_rows, hq,
+                                                 strides, dot_mode)
+        plan.run(dev, qs if scoring else None, ks, vs, [t[0] for t in trip], [t[1] for t in trip])
+        return ([t[0][:, :, :kk + window] for t, kk in zip(trip, keeps)], [t[1][:, :, :kk + window] for t, kk in zip(trip, keeps)])
     qs = qs if qs is not None else [None] * len(ks)
     bp = BatchPlan(method, list(zip(qs, ks, vs)), window, keeps, kernel_size, pooling, tie_mode, return_indices,
                    dot_mode, q_rows, n_q_heads, outs)

@@ -9,7 +9,57 @@ import torch
 from transformers.cache_utils import DynamicLayer
 
 
-class CompressedDynamicLayer(DynamicLayer):
+def _placeholder_only(name):
+    """Setter of the computed `keys` / `values` properties: DynamicLayer's constructor assigns None (and its stock
+    lazy_initialization an empty tensor); anything else would be silently lost, so it is refused."""
+    def setter(self, value):
+        if value is not None and getattr(value, "numel", lambda: 1)() != 0:
+            raise AttributeError(f"{type(self).__name__}.{name} is computed from the layer's own buffers; DynamicLayer operations that "
+                                 "reassign it are overridden (batch reordering) or refused (crop, offload)")
+    return setter
+
+
+class _BatchOps:
+    """The DynamicLayer operations that work by REASSIGNING keys / values (transformers 5.15: reorder_cache, batch_repeat_interleave,
+    batch_select_indices — beam search, num_return_sequences, contrastive search — and offload / prefetch / reset), restated on the
+    layer's own buffers.  `_batch_tensors` names the attributes that carry a batch dimension in front."""
+    _batch_tensors = ()
+
+    def _map_batch(self, fn):
+        for name in self._batch_tensors:
+            t = getattr(self, name)
+            if t is not None:
+                setattr(self, name, fn(t))
+
+    def reorder_cache(self, beam_idx):
+        if self.get_seq_length() > 0:
+            self._map_batch(lambda t: t.index_select(0, beam_idx.to(t.device)))
+
+    def batch_repeat_interleave(self, repeats):
+        if self.get_seq_length() > 0:
+            self._map_batch(lambda t: t.repeat_interleave(repeats, dim=0))
+
+    def batch_select_indices(self, indices):
+        if self.get_seq_length() > 0:
+            self._map_batch(lambda t: t[indices, ...])
+
+    def offload(self):
+        raise NotImplementedError("a compressed cache stays in the device buffers its kernels append to in place: no offloading")
+
+    def prefetch(self):
+        pass                                                            # never offloaded
+
+    def lazy_initialization(self, key_states, value_states=None):
+        """DynamicLayer's version also allocates two empty placeholder tensors for `keys` / `values`; here those are computed
+        properties, so only the bookkeeping is kept (two allocations per layer and prompt less on the prefill path)."""
+        self.dtype, self.device = key_states.dtype, key_states.device
+        self.is_initialized = True
+
+    def crop(self, *a, **kw):
+        raise NotImplementedError("a compressed cache cannot be cropped by position")
+
+
+class CompressedDynamicLayer(_BatchOps, DynamicLayer):
     """The compressed prompt of one layer plus the decoded tokens, in one of two forms.
 
     EXPANDED (the reference's form): `[bsz, H_q, stored, D]` — H_q heads like the reference's cache after repeat_kv.  The
@@ -35,21 +85,15 @@ class CompressedDynamicLayer(DynamicLayer):
 
     # ---- the reference's view --------------------------------------------------------------------------------------
     # (`keys` / `values` are plain attributes of DynamicLayer; here they are computed from the buffers)
-    @property
-    def keys(self):
-        return self._view(self._kbuf, self._ktail)
+    keys = property(lambda self: self._view(self._kbuf, self._ktail), _placeholder_only("keys"))
+    values = property(lambda self: self._view(self._vbuf, self._vtail), _placeholder_only("values"))
+    _batch_tensors = ("_kbuf", "_vbuf", "_ktail", "_vtail")
 
-    @keys.setter
-    def keys(self, value):              # DynamicLayer.lazy_initialization assigns empty tensors
-        pass
-
-    @property
-    def values(self):
-        return self._view(self._vbuf, self._vtail)
-
-    @values.setter
-    def values(self, value):
-        pass
+    def reset(self):
+        """Back to an empty layer (the next forward is a prefill): buffers, lengths and the split state go."""
+        self._kbuf = self._vbuf = self._ktail = self._vtail = None
+        self._stored = self._tail = self.true_length = 0
+        self._split = False
 
     def _view(self, buf, tail):
         if buf is None:
@@ -76,6 +120,21 @@ class CompressedDynamicLayer(DynamicLayer):
         self._vbuf = torch.empty_like(self._kbuf)
         self._stored = 0
         return self._kbuf, self._vbuf
+
+    @classmethod
+    def reserve_many(cls, layers, bsz, n_heads, capacities, head_dim, dtype, device):
+        """`reserve` for a group of layers out of ONE allocation (the grouped flush of PrefillBatch: one torch.empty and one
+        stream bookkeeping call per group instead of two per layer).  The slab lives as long as any layer's views do."""
+        per = [bsz * n_heads * c * head_dim for c in capacities]
+        slab = torch.empty(2 * sum(per), dtype=dtype, device=device)
+        outs, off = [], 0
+        for layer, c, n in zip(layers, capacities, per):
+            layer._kbuf = slab[off:off + n].view(bsz, n_heads, c, head_dim)
+            layer._vbuf = slab[off + n:off + 2 * n].view(bsz, n_heads, c, head_dim)
+            layer._stored = 0
+            outs.append((layer._kbuf, layer._vbuf))
+            off += 2 * n
+        return slab, outs
 
     def prefill(self, k_compressed, v_compressed, true_length):
         if not self.is_initialized:
@@ -155,11 +214,8 @@ class CompressedDynamicLayer(DynamicLayer):
         # the mask must be as wide as what attention will really see: stored tokens + the new ones
         return self.stored_length() + query_length, 0
 
-    def crop(self, *a, **kw):
-        raise NotImplementedError("a compressed cache cannot be cropped by position")
 
-
-class RaggedDynamicLayer(DynamicLayer):
+class RaggedDynamicLayer(_BatchOps, DynamicLayer):
     """The flattened cache of AdaKV / HeadKV for one layer — counterpart of the reference's DynamicCacheSplitHeadFlatten
     (pyramidkv_utils.py:28-102), whose every decode step allocates a new tensor and re-copies the whole cache with one row
     inserted per head (update_flatten_view, csrc/csrc/cuda_api.cu:12-85).  Here every head's segment has spare rows behind it
@@ -171,8 +227,18 @@ class RaggedDynamicLayer(DynamicLayer):
         self.k_flat = self.v_flat = self.seg_off = self.seg_len = None
         self.lens, self.slack, self.appended = [], 0, 0
 
-    keys = property(lambda self: self.k_flat, lambda self, v: None)
-    values = property(lambda self: self.v_flat, lambda self, v: None)
+    keys = property(lambda self: self.k_flat, _placeholder_only("keys"))
+    values = property(lambda self: self.v_flat, _placeholder_only("values"))
+
+    def _no_batch(self, *a, **kw):
+        # the flattened cache has no batch dimension to reorder (the reference's DynamicCacheSplitHeadFlatten has none either, and
+        # its README lists batch inference as unsupported): refuse instead of decoding against un-reordered histories
+        raise NotImplementedError("AdaKV / HeadKV keep one flattened cache per layer: beam search / num_return_sequences > 1 are not supported")
+    reorder_cache = batch_repeat_interleave = batch_select_indices = _no_batch
+
+    def reset(self):
+        self.k_flat = self.v_flat = self.seg_off = self.seg_len = None
+        self.lens, self.slack, self.appended, self.true_length = [], 0, 0, 0
 
     def prefill(self, ragged, true_length):
         if not self.is_initialized:
@@ -220,11 +286,8 @@ class RaggedDynamicLayer(DynamicLayer):
     def get_mask_sizes(self, query_length):
         return max(self.lens or [0]) + self.appended + query_length, 0
 
-    def crop(self, *a, **kw):
-        raise NotImplementedError("a compressed cache cannot be cropped by position")
 
-
-class ThinkDynamicLayer(DynamicLayer):
+class ThinkDynamicLayer(_BatchOps, DynamicLayer):
     """ThinK's cache for one layer — counterpart of the reference's cache_utils_think.DynamicCache (key_cache_pruned, mask,
     key_cache, value_cache; `update_think`, llama_model_think.py:167-168): the compressed keys are stored WITHOUT their pruned
     channels except the last `recent_size` rows; decoded tokens join the full-channel rows.  A decode step attends over
@@ -240,13 +303,19 @@ class ThinkDynamicLayer(DynamicLayer):
         self._kbuf = self._vbuf = None  # [bsz, H, capacity, D]: recent + decoded keys / all values
         self._kn = self._vn = 0
 
-    keys = property(lambda self: None if self._kbuf is None else self._kbuf[:, :, :self._kn], lambda self, v: None)
-    values = property(lambda self: None if self._vbuf is None else self._vbuf[:, :, :self._vn], lambda self, v: None)
+    keys = property(lambda self: None if self._kbuf is None else self._kbuf[:, :, :self._kn], _placeholder_only("keys"))
+    values = property(lambda self: None if self._vbuf is None else self._vbuf[:, :, :self._vn], _placeholder_only("values"))
+    _batch_tensors = ("key_pruned", "mask", "_kbuf", "_vbuf")
 
-    def _store(self, k_full, v_all):
+    def reset(self):
+        self.key_pruned = self.mask = self._kbuf = self._vbuf = None
+        self._kn = self._vn = self.true_length = 0
+
+    def _store(self, k_full, v_all, spare=0):
         b, h, _, d = v_all.shape
-        self._kbuf = torch.empty(b, h, k_full.shape[2] + self.RESERVE, d, dtype=v_all.dtype, device=v_all.device)
-        self._vbuf = torch.empty(b, h, v_all.shape[2] + self.RESERVE, d, dtype=v_all.dtype, device=v_all.device)
+        spare = max(self.RESERVE, spare)
+        self._kbuf = torch.empty(b, h, k_full.shape[2] + spare, d, dtype=v_all.dtype, device=v_all.device)
+        self._vbuf = torch.empty(b, h, v_all.shape[2] + spare, d, dtype=v_all.dtype, device=v_all.device)
         self._kn, self._vn = k_full.shape[2], v_all.shape[2]
         self._kbuf[:, :, :self._kn].copy_(k_full)
         self._vbuf[:, :, :self._vn].copy_(v_all)
@@ -270,7 +339,7 @@ class ThinkDynamicLayer(DynamicLayer):
         """Append the step's H-head rows and return the attention output [bsz, t, H, D] (llama_model_think.py:170-196)."""
         t = k_new.shape[2]
         if self._kn + t > self._kbuf.shape[2] or self._vn + t > self._vbuf.shape[2]:
-            self._store(self.keys, self.values)                           # fresh buffers with RESERVE spare rows again
+            self._store(self.keys, self.values, 2 * t)                    # fresh buffers with spare rows again (>= RESERVE, >= this step)
         self._kbuf[:, :, self._kn:self._kn + t].copy_(k_new)
         self._vbuf[:, :, self._vn:self._vn + t].copy_(v_new)
         self._kn += t
@@ -297,6 +366,3 @@ class ThinkDynamicLayer(DynamicLayer):
 
     def get_mask_sizes(self, query_length):
         return self._vn + query_length, 0
-
-    def crop(self, *a, **kw):
-        raise NotImplementedError("a compressed cache cannot be cropped by position")

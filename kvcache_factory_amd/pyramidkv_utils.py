@@ -120,7 +120,8 @@ class PrefillBatch:
 
     def __init__(self):
         self.entries = []
-        self._events = []               # (event recorded on the side stream, tensors the current stream will read)
+        self._events = []               # (event recorded on the side stream, device, output tensors, input tensors kept alive)
+        self._flushes = 0
 
     def __len__(self):
         return len(self.entries)
@@ -143,63 +144,83 @@ class PrefillBatch:
         if scoring and cluster.pooling not in ("avgpool", "maxpool"):
             raise ValueError('Pooling method not supported')            # pyramidkv_utils.py:333
         W = cluster.window_size
-        qw = query_states[:, :, q_len - W:, :].contiguous() if scoring else None
+        # the W scoring rows are read where the projection left them (a view: the library takes q_stride_h / q_stride_l);
+        # round 2 copied them out per layer — a kernel launch and an allocation per update_kv on the host's critical path
+        qw = _kvc._last_dim_contig(query_states)[:, :, q_len - W:, :] if scoring else None
         k, v = _kvc._last_dim_contig(key_states), _kvc._last_dim_contig(value_states)
-        layout = (cluster._method, tuple(k.shape), k.stride(), v.stride(), k.dtype, k.device, num_heads, W,
-                  cluster.kernel_size if scoring else 0, cluster.pooling if scoring else None)
+        layout = (cluster._method, tuple(k.shape), k.stride(), v.stride(), qw.stride() if scoring else None, k.dtype, k.device,
+                  num_heads, W, cluster.kernel_size if scoring else 0, cluster.pooling if scoring else None)
         self.entries.append((tag, layout, k, qw, v, n_keep, sink, alloc))
         return True
+
+    def _release_done(self):
+        """Inputs of earlier overlapped flushes whose side-stream work has finished are let go (their memory returns to the
+        producing stream's pool; no record_stream bookkeeping per tensor)."""
+        for i, (ev, dev, outs, held) in enumerate(self._events):
+            if held is not None and ev.query():
+                self._events[i] = (ev, dev, outs, None)
 
     def flush(self, overlap=False):
         entries, self.entries = self.entries, []
         groups = {}
         for e in entries:
             groups.setdefault(e[1], []).append(e)
+        self._release_done()
         for layout, es in groups.items():
-            method, _, _, _, _, dev, num_heads, W, kernel_size, pooling = layout
+            method, kshape, _, _, _, dtype, dev, num_heads, W, kernel_size, pooling = layout
             scoring = method != _kvc.STREAMINGLLM
-            side = _side_stream(dev) if (overlap and OVERLAP and dev.type == "cuda") else None
-            if side is not None:
-                side.wait_stream(torch.cuda.current_stream(dev))        # K, V and the query rows are complete
+            keeps = tuple(e[5] for e in es)
+            owned = all(e[7] is not None for e in es)
+            side = None
+            # overlapped only when the outputs go into owner-provided buffers: a sink that is handed FRESH tensors may read them
+            # on its own stream right away (e.g. copy them into a cache) while the side stream is still writing
+            if overlap and OVERLAP and owned and dev.type == "cuda":
+                side = _side_stream(dev, self._flushes % N_SIDE_STREAMS)    # alternating: this group's latency-bound top-k runs
+                self._flushes += 1                                          # beside the next group's K scan
+                side.wait_stream(torch.cuda.current_stream(dev))            # K, V and the query rows are complete
                 ctx = torch.cuda.stream(side)
             else:
                 ctx = contextlib.nullcontext()
             with ctx:
-                outs = None
-                if all(e[7] is not None for e in es):       # every layer's cache sized for its OWN budget (per-item strides)
-                    k0 = es[0][2]
-                    outs = [e[7](k0.shape[0], num_heads, e[5] + W + SPARE_ROWS, k0.shape[3], k0.dtype, k0.device) for e in es]
+                slab, outs = None, None
+                if owned:                                   # every layer's cache sized for its OWN budget (per-item strides)
+                    caps = [kk + W + SPARE_ROWS for kk in keeps]
+                    owners = [getattr(e[7], "__self__", None) for e in es]
+                    many = getattr(type(owners[0]), "reserve_many", None) if owners[0] is not None else None
+                    if many is not None and all(type(o) is type(owners[0]) for o in owners):
+                        slab, outs = many(owners, kshape[0], num_heads, caps, kshape[3], dtype, dev)
+                    else:
+                        outs = [e[7](kshape[0], num_heads, c, kshape[3], dtype, dev) for e, c in zip(es, caps)]
                 kc, vc = _kvc.compress_batch(method, [e[3] for e in es] if scoring else None, [e[2] for e in es],
-                                             [e[4] for e in es], W, [e[5] for e in es], kernel_size, pooling, TIE_MODE,
-                                             q_rows="window" if scoring else "all", n_q_heads=num_heads, outs=outs)
+                                             [e[4] for e in es], W, keeps, kernel_size, pooling, TIE_MODE,
+                                             q_rows="window" if scoring else "all", n_q_heads=num_heads, outs=outs, reuse=True)
             if side is not None:
-                for e in es:                                # inputs were allocated on the producing stream: keep their
-                    for t in (e[2], e[3], e[4]):            # memory until the side stream is done with them
-                        if t is not None:
-                            t.record_stream(side)
                 ev = torch.cuda.Event()
                 ev.record(side)
-                self._events.append((ev, dev, [t for o in (outs or zip(kc, vc)) for t in o]))
+                # inputs were allocated on the producing stream: they are held until the side stream has passed this event
+                self._events.append((ev, dev, [slab] if slab is not None else [t for o in outs for t in o],
+                                     [t for e in es for t in (e[2], e[3], e[4]) if t is not None]))
             for e, a, b in zip(es, kc, vc):
                 e[6](a, b)
 
     def settle(self):
         """The current stream waits for every overlapped flush (no host synchronisation)."""
-        for ev, dev, outs in self._events:
+        for ev, dev, outs, held in self._events:
             cur = torch.cuda.current_stream(dev)
-            cur.wait_event(ev)
-            for t in outs:
+            cur.wait_event(ev)              # (whatever the current stream does to the held inputs' memory from here on is ordered
+            for t in outs:                  # behind the side stream's reads: they may be dropped with this list)
                 t.record_stream(cur)
         self._events = []
 
 
+N_SIDE_STREAMS = 2
 _SIDE = {}
 
 
-def _side_stream(dev):
-    if dev not in _SIDE:
-        _SIDE[dev] = torch.cuda.Stream(device=dev)
-    return _SIDE[dev]
+def _side_stream(dev, i=0):
+    if (dev, i) not in _SIDE:
+        _SIDE[(dev, i)] = torch.cuda.Stream(device=dev)
+    return _SIDE[(dev, i)]
 
 
 class SnapKVCluster(_KVCluster):

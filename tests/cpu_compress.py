@@ -28,7 +28,7 @@ def oracle_compress(method, q, k, v, window, n_keep, kernel_size=5, pooling="avg
 
 
 def oracle_compress_batch(method, qs, ks, vs, window, keeps, kernel_size=5, pooling="avgpool", tie_mode="torch_cpu",
-                          q_rows="all", n_q_heads=None, return_indices=False, dot_mode=None, outs=None):
+                          q_rows="all", n_q_heads=None, return_indices=False, dot_mode=None, outs=None, reuse=False):
     """Stand-in for _kvc.compress_batch: the items one after the other through oracle_compress."""
     ko, vo, ix = [], [], []
     for i, (k, v) in enumerate(zip(ks, vs)):

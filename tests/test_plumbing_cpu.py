@@ -287,6 +287,55 @@ def test_decode_appends_in_place(cpu_backend):
     assert layer._kbuf.data_ptr() != ptr and layer._kbuf.shape[2] >= 18  # grew by doubling
 
 
+def test_batch_reordering_works_on_the_layers_own_buffers(cpu_backend):
+    """Beam search / num_return_sequences / contrastive search drive DynamicLayer.reorder_cache, batch_repeat_interleave and
+    batch_select_indices, which stock transformers implements by REASSIGNING keys / values.  Those are computed properties
+    here: the operations are restated on the buffers (prefix, spare rows, split tail), anything that would assign a real tensor to
+    keys / values is refused instead of silently lost, reset() really empties the layer, the ragged cache (no batch dimension,
+    as in the reference) refuses, and crop / offload raise."""
+    from kvcache_factory_amd.cache import CompressedDynamicLayer, RaggedDynamicLayer, ThinkDynamicLayer
+    g = torch.Generator().manual_seed(3)
+    k0, v0 = torch.randn(3, 4, 10, 8, generator=g), torch.randn(3, 4, 10, 8, generator=g)
+    layer = CompressedDynamicLayer()
+    layer.prefill(k0, v0, 100)
+    kn, vn = torch.randn(3, 4, 1, 8, generator=g), torch.randn(3, 4, 1, 8, generator=g)
+    layer.update(kn, vn)
+    ref_k, ref_v = torch.cat([k0, kn], 2), torch.cat([v0, vn], 2)
+    beam = torch.tensor([2, 0, 0])
+    layer.reorder_cache(beam)
+    assert torch.equal(layer.keys, ref_k[beam]) and torch.equal(layer.values, ref_v[beam]) and layer.get_seq_length() == 101
+    kn2, vn2 = torch.randn(3, 4, 1, 8, generator=g), torch.randn(3, 4, 1, 8, generator=g)
+    ko, vo = layer.update(kn2, vn2)                                    # decoding goes on against the reordered histories
+    assert torch.equal(ko, torch.cat([ref_k[beam], kn2], 2)) and torch.equal(vo, torch.cat([ref_v[beam], vn2], 2))
+    layer.batch_repeat_interleave(2)
+    assert layer.keys.shape[0] == 6 and torch.equal(layer.keys[1], ko[0]) and torch.equal(layer.keys[2], ko[1])
+    layer.batch_select_indices(torch.tensor([0, 5]))
+    assert layer.keys.shape[0] == 2 and torch.equal(layer.keys[1], ko[2])
+    with pytest.raises(AttributeError):
+        layer.keys = k0                                                # would have been a silent no-op
+    with pytest.raises(NotImplementedError):
+        layer.crop(-1)
+    with pytest.raises(NotImplementedError):
+        layer.offload()
+    layer.reset()
+    assert layer.get_seq_length() == 0 and layer.keys is None and layer.stored_length() == 0 and not layer.can_split()
+    # ThinK's two-part cache reorders every part
+    t = ThinkDynamicLayer()
+    t.prefill_think(torch.randn(3, 4, 6, 5, generator=g), k0, torch.rand(3, 4, 8, generator=g) > 0.4, v0, 50)
+    kp, m, kk = t.key_pruned.clone(), t.mask.clone(), t.keys.clone()
+    t.reorder_cache(beam)
+    assert torch.equal(t.key_pruned, kp[beam]) and torch.equal(t.mask, m[beam]) and torch.equal(t.keys, kk[beam])
+    t.reset()
+    assert t.get_seq_length() == 0 and t.keys is None
+    r = RaggedDynamicLayer()
+    r.prefill(dict(k_flat=torch.zeros(5, 8), v_flat=torch.zeros(5, 8), seg_off=torch.tensor([0]), seg_len=torch.tensor([5]), lens=[5], slack=0), 9)
+    for op, arg in ((r.reorder_cache, beam), (r.batch_repeat_interleave, 2), (r.batch_select_indices, beam)):
+        with pytest.raises(NotImplementedError):
+            op(arg)
+    r.reset()
+    assert r.get_seq_length() == 0 and r.keys is None
+
+
 def test_prefill_batch_groups_by_layout(cpu_backend, monkeypatch):
     """PrefillBatch.flush issues one compress_batch per group of entries that share a layout (shape, strides, dtype, window,
     pooling ...); sinks receive their own results in the order the entries were added; H2O and pass-through are refused."""
