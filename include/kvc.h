@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define KVC_VERSION 4
+#define KVC_VERSION 5
 
 typedef enum kvc_status {
     KVC_OK = 0,
@@ -204,6 +204,28 @@ typedef struct kvc_decode_params {
 int kvc_decode_step(const kvc_decode_params* p, const void* q, const void* k_new, const void* v_new,
                     const void* k_prefix, const void* v_prefix, void* k_tail, void* v_tail, void* out, void* hip_stream);
 
+/* kvc_decode_step2 (ABI 5): the same step with
+ *   - a workspace, so that the rows of one head are shared by several workgroups and merged afterwards (a decode step over a
+ *     2 056-row cache reads 1 MB per head: with one workgroup per head 7/8 of the chip idles — 80 us -> see profiles/r03_decode*);
+ *     kvc_decode_workspace_bytes(p, ext) says how much; less (or NULL) only reduces the number of splits;
+ *   - optionally (ext != NULL) separate strides for v_prefix and ThinK's channel-pruned leading rows
+ *     (llama_model_think.py:160-200, cache_utils_think.py:390-424): the first `pruned_rows` rows of a head have their keys in
+ *     k_pruned [b][h_q][pruned_rows][pruned_dim] — only the kept channels, in ascending channel order, zero-padded to a multiple of
+ *     16 bytes — and are scored against the query's channels chan[b][h_q][0..pruned_dim) (int16, -1 = padding column); their
+ *     values are rows [0, pruned_rows) of v_prefix, the full-channel prefix keys k_prefix[0..prefix_rows) pair with
+ *     v_prefix rows [pruned_rows, pruned_rows + prefix_rows). */
+typedef struct kvc_decode_ext {
+    int64_t v_prefix_stride_b, v_prefix_stride_h;           /* v_prefix [b][h_q][row][:]; 0 = the same as prefix_stride_* */
+    int32_t pruned_rows, pruned_dim;
+    int64_t pruned_stride_b, pruned_stride_h;               /* k_pruned [b][h_q][row][pruned_dim] */
+    int64_t chan_stride_b, chan_stride_h;                   /* chan [b][h_q][pruned_dim] (elements of int16) */
+} kvc_decode_ext;
+size_t kvc_decode_workspace_bytes(const kvc_decode_params* p, const kvc_decode_ext* ext /* nullable */);
+int kvc_decode_step2(const kvc_decode_params* p, const kvc_decode_ext* ext /* nullable */, const void* q, const void* k_new, const void* v_new,
+                     const void* k_prefix, const void* v_prefix, void* k_tail, void* v_tail,
+                     const void* k_pruned /* nullable */, const int16_t* chan /* nullable */, void* out,
+                     void* workspace /* nullable */, size_t workspace_bytes, void* hip_stream);
+
 /* ---- AdaKV / HeadKV: per-head budgets, ragged ("flattened") cache -----------------------------------
  * Replaces AdaKVCluster.update_kv (pyramidkv_utils.py:674-757), HeadKVCluster.update_kv (:813-878) and, at decode, the
  * repo's native update_flatten_view (csrc/csrc/cuda_api.cu:12-85) + flash_attn_varlen_func (llama_model.py:2363-2390).
@@ -234,6 +256,8 @@ typedef struct kvc_ragged_decode_params {
     int64_t q_stride_b, q_stride_h, q_stride_l;             /* q[b][h_q][i][:] */
     int64_t new_stride_b, new_stride_h, new_stride_l;       /* k_new / v_new [b][h_kv][i][:] */
     int64_t out_stride_b, out_stride_h, out_stride_l;       /* out[b][h_q][i][:] */
+    int32_t slack_rows;        /* ABI 5: spare rows behind every segment (0 = not checked): appended + new_rows beyond it is refused */
+    int32_t reserved;
 } kvc_ragged_decode_params;
 int kvc_ragged_decode_step(const kvc_ragged_decode_params* p, const void* q, const void* k_new, const void* v_new,
                            void* k_flat, void* v_flat, const int64_t* seg_off, const int32_t* seg_len, void* out, void* hip_stream);

@@ -25,7 +25,7 @@ EXPORTS = ("kvc_version", "kvc_last_error", "kvc_workspace_bytes", "kvc_compress
            "kvc_gather", "kvc_pyramid_k", "kvc_workspace_layout", "kvc_workspace_bytes_batch", "kvc_compress_batch",
            "kvc_select_workspace_bytes", "kvc_decode_step", "kvc_ragged_workspace_bytes", "kvc_ragged_plan",
            "kvc_ragged_compact", "kvc_ragged_decode_step", "kvc_l2norm_workspace_bytes", "kvc_l2norm_compress",
-           "kvc_merge_workspace_bytes", "kvc_merge_pivot", "kvc_think_prune")
+           "kvc_merge_workspace_bytes", "kvc_merge_pivot", "kvc_think_prune", "kvc_decode_workspace_bytes", "kvc_decode_step2")
 
 
 class KvcError(RuntimeError):
@@ -60,7 +60,13 @@ class RaggedDecodeParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("dtype", "bsz", "n_q_heads", "n_kv_heads", "head_dim", "appended", "new_rows")] + [
         ("scaling", ctypes.c_float)] + [(n, ctypes.c_int64) for n in (
             "q_stride_b", "q_stride_h", "q_stride_l", "new_stride_b", "new_stride_h", "new_stride_l",
-            "out_stride_b", "out_stride_h", "out_stride_l")]
+            "out_stride_b", "out_stride_h", "out_stride_l")] + [("slack_rows", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class DecodeExt(ctypes.Structure):
+    _fields_ = [("v_prefix_stride_b", ctypes.c_int64), ("v_prefix_stride_h", ctypes.c_int64), ("pruned_rows", ctypes.c_int32),
+                ("pruned_dim", ctypes.c_int32), ("pruned_stride_b", ctypes.c_int64), ("pruned_stride_h", ctypes.c_int64),
+                ("chan_stride_b", ctypes.c_int64), ("chan_stride_h", ctypes.c_int64)]
 
 
 _lib = None
@@ -91,6 +97,9 @@ def lib():
         L.kvc_workspace_bytes_batch.restype = sz
         L.kvc_compress_batch.argtypes = [pp, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         L.kvc_decode_step.argtypes = [ctypes.POINTER(DecodeParams)] + [vp] * 9
+        L.kvc_decode_workspace_bytes.argtypes = [ctypes.POINTER(DecodeParams), ctypes.POINTER(DecodeExt)]
+        L.kvc_decode_workspace_bytes.restype = sz
+        L.kvc_decode_step2.argtypes = [ctypes.POINTER(DecodeParams), ctypes.POINTER(DecodeExt)] + [vp] * 11 + [sz, vp]
         L.kvc_ragged_workspace_bytes.argtypes = [pp]
         L.kvc_ragged_workspace_bytes.restype = sz
         L.kvc_ragged_plan.argtypes = [pp, vp, vp, ctypes.c_float, ctypes.c_int, vp, vp, vp, vp, sz, vp]
@@ -306,18 +315,21 @@ def gather(src, idx, window, n_q_heads):
     return out
 
 
-def decode_step(q, k_new, v_new, k_prefix, v_prefix, prefix_rows, k_tail, v_tail, tail_rows, scaling):
-    """One decode step over the compacted cache (kvc_decode_step): appends k_new / v_new [b, H_kv, t, D] to the tail buffers
+def decode_step(q, k_new, v_new, k_prefix, v_prefix, prefix_rows, k_tail, v_tail, tail_rows, scaling, k_pruned=None, chan=None,
+                pruned_rows=0):
+    """One decode step over the compacted cache (kvc_decode_step2): appends k_new / v_new [b, H_kv, t, D] to the tail buffers
     [b, H_kv, capacity, D] at row tail_rows and returns the attention output [b, t, H_q, D] of q [b, H_q, t, D] over the
-    first prefix_rows rows per query head of k_prefix / v_prefix [b, H_q, >= prefix_rows, D] and the tail."""
+    first prefix_rows rows per query head of k_prefix / v_prefix [b, H_q, >= rows, D] and the tail.
+    ThinK (k_pruned [b, H_q, pruned_rows, Dk_padded], chan [b, H_q, Dk_padded] int16): the first pruned_rows rows' keys hold only
+    the kept channels; their values are rows [0, pruned_rows) of v_prefix and k_prefix's rows pair with the v_prefix rows behind."""
     _require_gpu(q, k_new, v_new, k_prefix, v_prefix, k_tail, v_tail)
-    dev = _one_device(q, k_new, v_new, k_prefix, v_prefix, k_tail, v_tail)
+    dev = _one_device(q, k_new, v_new, k_prefix, v_prefix, k_tail, v_tail, k_pruned, chan)
     q, k_new, v_new = _last_dim_contig(q), _last_dim_contig(k_new), _last_dim_contig(v_new)
     if k_new.stride() != v_new.stride():        # K comes out of RoPE contiguous, V is the projection's transposed view
         k_new, v_new = k_new.contiguous(), v_new.contiguous()
     b, hq, t, D = q.shape
     assert k_tail.shape[2] >= tail_rows + t and k_new.shape == v_new.shape and k_new.shape[2] == t
-    assert k_tail.stride() == v_tail.stride() and k_prefix.stride() == v_prefix.stride()
+    assert k_tail.stride() == v_tail.stride()
     for x in (k_prefix, v_prefix, k_tail, v_tail):
         assert x.stride(3) == 1 and x.stride(2) == D, "cache rows must be dense"
     out = torch.empty(b, t, hq, D, dtype=q.dtype, device=dev)
@@ -329,8 +341,18 @@ def decode_step(q, k_new, v_new, k_prefix, v_prefix, prefix_rows, k_tail, v_tail
     p.prefix_stride_b, p.prefix_stride_h = k_prefix.stride(0), k_prefix.stride(1)
     p.tail_stride_b, p.tail_stride_h = k_tail.stride(0), k_tail.stride(1)
     p.out_stride_b, p.out_stride_h, p.out_stride_l = out.stride(0), out.stride(2), out.stride(1)
-    _check(_call(dev, lib().kvc_decode_step, ctypes.byref(p), _ptr(q), _ptr(k_new), _ptr(v_new), _ptr(k_prefix), _ptr(v_prefix),
-                 _ptr(k_tail), _ptr(v_tail), _ptr(out), _stream(dev)))
+    x = DecodeExt()
+    x.v_prefix_stride_b, x.v_prefix_stride_h = v_prefix.stride(0), v_prefix.stride(1)
+    if pruned_rows:
+        assert k_pruned.is_contiguous() and chan.is_contiguous() and chan.dtype == torch.int16 and chan.shape[-1] == k_pruned.shape[-1]
+        x.pruned_rows, x.pruned_dim = pruned_rows, k_pruned.shape[3]
+        x.pruned_stride_b, x.pruned_stride_h = k_pruned.stride(0), k_pruned.stride(1)
+        x.chan_stride_b, x.chan_stride_h = chan.stride(0), chan.stride(1)
+    nbytes = lib().kvc_decode_workspace_bytes(ctypes.byref(p), ctypes.byref(x))
+    ws = workspace(dev, nbytes) if nbytes else None
+    _check(_call(dev, lib().kvc_decode_step2, ctypes.byref(p), ctypes.byref(x), _ptr(q), _ptr(k_new), _ptr(v_new), _ptr(k_prefix),
+                 _ptr(v_prefix), _ptr(k_tail), _ptr(v_tail), _ptr(k_pruned if pruned_rows else None), _ptr(chan if pruned_rows else None),
+                 _ptr(out), _ptr(ws), nbytes, _stream(dev)))
     return out
 
 
@@ -378,7 +400,7 @@ def ragged_compress(method, q, k, v, window, base_capacity, kernel_size=7, pooli
                 seg_len=(caps + window).to(torch.int32), flag=flags[:, 0], idx=idx, scores=sc, slack=slack)
 
 
-def ragged_decode_step(q, k_new, v_new, k_flat, v_flat, seg_off, seg_len, appended, scaling):
+def ragged_decode_step(q, k_new, v_new, k_flat, v_flat, seg_off, seg_len, appended, scaling, slack=0):
     """One decode step over the ragged cache (kvc_ragged_decode_step): k_new / v_new [b, H_kv, t, D] are written behind every
     query head's segment (row seg_off + seg_len + appended) and the attention output [b, t, H_q, D] comes back."""
     _require_gpu(q, k_new, v_new, k_flat, v_flat)
@@ -390,7 +412,7 @@ def ragged_decode_step(q, k_new, v_new, k_flat, v_flat, seg_off, seg_len, append
     out = torch.empty(b, t, hq, D, dtype=q.dtype, device=dev)
     p = RaggedDecodeParams()
     p.dtype, p.bsz, p.n_q_heads, p.n_kv_heads, p.head_dim = DTYPES[q.dtype], b, hq, k_new.shape[1], D
-    p.appended, p.new_rows, p.scaling = appended, t, scaling
+    p.appended, p.new_rows, p.scaling, p.slack_rows = appended, t, scaling, slack
     p.q_stride_b, p.q_stride_h, p.q_stride_l = q.stride(0), q.stride(1), q.stride(2)
     p.new_stride_b, p.new_stride_h, p.new_stride_l = k_new.stride(0), k_new.stride(1), k_new.stride(2)
     p.out_stride_b, p.out_stride_h, p.out_stride_l = out.stride(0), out.stride(2), out.stride(1)

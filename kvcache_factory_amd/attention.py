@@ -205,7 +205,7 @@ def make_think_forward(apply_rotary_pos_emb, eager_attention_forward, repeat_kv)
     """ThinK forward — counterpart of llama_attn_forward_SnapKV_ThinK (llama_model_think.py:86-218): prefill compresses with
     SnapKV and prunes key channels (kv_cluster.update_think, on the GPU through kvc_compress + kvc_think_prune) into a
     ThinkDynamicLayer; this step's attention runs over the uncompressed K/V; a decode step attends over [channel-pruned rows |
-    recent + decoded rows] with torch ops, as the reference does (:175-196)."""
+    recent + decoded rows] in one kvc_decode_step2 call (the reference: two matmuls, cat, softmax, matmul, :175-196)."""
 
     def forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None, **kwargs):
         pu.init_think(self)
@@ -236,8 +236,7 @@ def make_think_forward(apply_rotary_pos_emb, eager_attention_forward, repeat_kv)
                 else:
                     layer.prefill_think(*res, q_len)
             else:                                                            # decode
-                out = layer.attend(query_states, repeat_kv(key_states, self.num_key_value_groups),
-                                   repeat_kv(value_states, self.num_key_value_groups), self.scaling)
+                out = layer.attend(query_states, key_states, value_states, self.scaling)   # H_kv-head rows: the tail holds them once
                 return self.o_proj(out.reshape(*input_shape, -1)), None
         attention_interface: Callable = ALL_ATTENTION_FUNCTIONS.get_interface(
             self.config._attn_implementation, eager_attention_forward)

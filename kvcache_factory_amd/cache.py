@@ -270,7 +270,7 @@ class RaggedDynamicLayer(_BatchOps, DynamicLayer):
         if self.appended + t > self.slack:
             self._regrow(self.appended + t)
         out = _kvc.ragged_decode_step(query_states, key_states, value_states, self.k_flat, self.v_flat, self.seg_off, self.seg_len,
-                                      self.appended, scaling)
+                                      self.appended, scaling, slack=self.slack)
         self.appended += t
         self.true_length += t
         return out
@@ -289,80 +289,94 @@ class RaggedDynamicLayer(_BatchOps, DynamicLayer):
 
 class ThinkDynamicLayer(_BatchOps, DynamicLayer):
     """ThinK's cache for one layer — counterpart of the reference's cache_utils_think.DynamicCache (key_cache_pruned, mask,
-    key_cache, value_cache; `update_think`, llama_model_think.py:167-168): the compressed keys are stored WITHOUT their pruned
-    channels except the last `recent_size` rows; decoded tokens join the full-channel rows.  A decode step attends over
-    [pruned rows | recent + decoded rows] with the query's kept channels for the first part (llama_model_think.py:175-182).
-    Rows are appended in place into buffers with spare rows."""
+    key_cache, value_cache; `update_think`, cache_utils_think.py:390-424, llama_model_think.py:167-168): the compressed keys are
+    stored WITHOUT their pruned channels except the last `recent_size` rows; decoded tokens join the full-channel rows.  A decode
+    step attends over [pruned rows | recent + decoded rows] with the query's kept channels for the first part
+    (llama_model_think.py:175-196) — here ONE kvc_decode_step2 call (round 2: two torch matmuls, a cat, a softmax and a matmul):
+    the pruned keys are kept once more in the kernel's form (kept channels in ascending order, zero-padded to 16 bytes, with the
+    channel list), the recent rows and all values stay where update_think wrote them, and the decoded tokens go to a tail stored
+    once per KV head and appended in place, as in CompressedDynamicLayer."""
     RESERVE = 256
 
     def __init__(self):
         super().__init__()
         self.true_length = 0
-        self.key_pruned = None          # [bsz, H, cap - recent, D - k] or None (pass-through prompt: nothing pruned)
+        self.key_pruned = None          # [bsz, H, P1, Dk] (the reference's layout) or None (pass-through prompt: nothing pruned)
         self.mask = None                # [bsz, H, D] bool, True = channel kept
-        self._kbuf = self._vbuf = None  # [bsz, H, capacity, D]: recent + decoded keys / all values
-        self._kn = self._vn = 0
+        self._kp = self._chan = None    # kernel form: [bsz, H, P1, Dk padded], [bsz, H, Dk padded] int16 (-1 = padding)
+        self._kbuf = self._vbuf = None  # recent keys [bsz, H, Pr, D]; ALL values of the compressed prompt [bsz, H, P1 + Pr, D]
+        self._ktail = self._vtail = None    # decoded tokens [bsz, H_kv, capacity, D]
+        self._tail = 0
 
-    keys = property(lambda self: None if self._kbuf is None else self._kbuf[:, :, :self._kn], _placeholder_only("keys"))
-    values = property(lambda self: None if self._vbuf is None else self._vbuf[:, :, :self._vn], _placeholder_only("values"))
-    _batch_tensors = ("key_pruned", "mask", "_kbuf", "_vbuf")
+    def _expanded(self, buf, tail):
+        if buf is None:
+            return None
+        if tail is None or self._tail == 0:
+            return buf
+        return torch.cat([buf, tail[:, :, :self._tail].repeat_interleave(buf.shape[1] // tail.shape[1], dim=1)], dim=2)
+
+    # the reference's views: key_cache (full-channel rows: recent + decoded) and value_cache (every row)
+    keys = property(lambda self: self._expanded(self._kbuf, self._ktail), _placeholder_only("keys"))
+    values = property(lambda self: self._expanded(self._vbuf, self._vtail), _placeholder_only("values"))
+    _batch_tensors = ("key_pruned", "mask", "_kp", "_chan", "_kbuf", "_vbuf", "_ktail", "_vtail")
 
     def reset(self):
-        self.key_pruned = self.mask = self._kbuf = self._vbuf = None
-        self._kn = self._vn = self.true_length = 0
-
-    def _store(self, k_full, v_all, spare=0):
-        b, h, _, d = v_all.shape
-        spare = max(self.RESERVE, spare)
-        self._kbuf = torch.empty(b, h, k_full.shape[2] + spare, d, dtype=v_all.dtype, device=v_all.device)
-        self._vbuf = torch.empty(b, h, v_all.shape[2] + spare, d, dtype=v_all.dtype, device=v_all.device)
-        self._kn, self._vn = k_full.shape[2], v_all.shape[2]
-        self._kbuf[:, :, :self._kn].copy_(k_full)
-        self._vbuf[:, :, :self._vn].copy_(v_all)
+        self.key_pruned = self.mask = self._kp = self._chan = self._kbuf = self._vbuf = self._ktail = self._vtail = None
+        self._tail = self.true_length = 0
 
     def prefill_think(self, kv_pruned, kv_recent, mask, values, true_length):
         if not self.is_initialized:
             self.lazy_initialization(kv_recent, values)
         self.key_pruned, self.mask = kv_pruned, mask
-        self._store(kv_recent, values)
+        b, h, p1, dk = kv_pruned.shape
+        per16 = 16 // kv_pruned.element_size()
+        dkp = (dk + per16 - 1) // per16 * per16
+        self._kp = torch.nn.functional.pad(kv_pruned, (0, dkp - dk)).contiguous()
+        # kept channels in ascending order (the order of key_states[mask], pyramidkv_utils.py:24-25): a stable sort of the mask
+        order = torch.sort(mask.to(torch.int8), dim=-1, descending=True, stable=True).indices[..., :dk]
+        self._chan = torch.nn.functional.pad(order.to(torch.int16), (0, dkp - dk), value=-1).contiguous()
+        self._kbuf, self._vbuf = kv_recent.contiguous(), values.contiguous()
+        self._ktail = self._vtail = None
+        self._tail = 0
         self.true_length = int(true_length)
 
     def prefill_plain(self, keys, values, true_length):
         """A prompt shorter than the budget (or a merged one): update_think returned plain (keys, values)."""
         if not self.is_initialized:
             self.lazy_initialization(keys, values)
-        self.key_pruned, self.mask = None, None
-        self._store(keys, values)
+        self.key_pruned = self.mask = self._kp = self._chan = None
+        self._kbuf, self._vbuf = keys.contiguous(), values.contiguous()
+        self._ktail = self._vtail = None
+        self._tail = 0
         self.true_length = int(true_length)
 
     def attend(self, query_states, k_new, v_new, scaling):
-        """Append the step's H-head rows and return the attention output [bsz, t, H, D] (llama_model_think.py:170-196)."""
-        t = k_new.shape[2]
-        if self._kn + t > self._kbuf.shape[2] or self._vn + t > self._vbuf.shape[2]:
-            self._store(self.keys, self.values, 2 * t)                    # fresh buffers with spare rows again (>= RESERVE, >= this step)
-        self._kbuf[:, :, self._kn:self._kn + t].copy_(k_new)
-        self._vbuf[:, :, self._vn:self._vn + t].copy_(v_new)
-        self._kn += t
-        self._vn += t
+        """The step's K/V rows [bsz, H_kv, t, D] go to the tail and the attention output [bsz, t, H, D] over pruned rows, recent
+        rows and tail comes back — kvc_decode_step2 (llama_model_think.py:170-196)."""
+        from . import _kvc
+        b, hkv, t, d = k_new.shape
+        if self._ktail is None:
+            self._ktail = torch.empty(b, hkv, max(self.RESERVE, 2 * t), d, dtype=k_new.dtype, device=k_new.device)
+            self._vtail = torch.empty_like(self._ktail)
+        if self._tail + t > self._ktail.shape[2]:                 # tail full: double it
+            cap = max(2 * self._ktail.shape[2], self._tail + t)
+            kt = torch.empty(b, hkv, cap, d, dtype=self._ktail.dtype, device=self._ktail.device)
+            vt = torch.empty_like(kt)
+            kt[:, :, :self._tail].copy_(self._ktail[:, :, :self._tail])
+            vt[:, :, :self._tail].copy_(self._vtail[:, :, :self._tail])
+            self._ktail, self._vtail = kt, vt
+        p1 = 0 if self._kp is None else self._kp.shape[2]
+        out = _kvc.decode_step(query_states, k_new, v_new, self._kbuf, self._vbuf, self._kbuf.shape[2], self._ktail, self._vtail,
+                               self._tail, scaling, k_pruned=self._kp, chan=self._chan, pruned_rows=p1)
+        self._tail += t
         self.true_length += t
-        logits = torch.matmul(query_states, self.keys.transpose(2, 3))
-        if self.key_pruned is not None:
-            b, h, _, d = query_states.shape
-            qm = query_states[self.mask.unsqueeze(2).expand(-1, -1, t, -1)].view(b, h, t, -1)
-            logits = torch.cat([torch.matmul(qm, self.key_pruned.transpose(2, 3)), logits], dim=-1)
-        logits = logits * scaling
-        if t > 1:                                                          # the step's own tokens are causal among themselves
-            n = logits.shape[-1]
-            causal = torch.full((t, t), torch.finfo(logits.dtype).min, device=logits.device, dtype=logits.dtype).triu(1)
-            logits[..., n - t:] = logits[..., n - t:] + causal
-        w = torch.nn.functional.softmax(logits, dim=-1, dtype=torch.float32).to(query_states.dtype)
-        return torch.matmul(w, self.values).transpose(1, 2)
+        return out
 
     def stored_length(self):
-        return self._vn
+        return (0 if self._vbuf is None else self._vbuf.shape[2]) + self._tail
 
     def get_seq_length(self):
         return self.true_length
 
     def get_mask_sizes(self, query_length):
-        return self._vn + query_length, 0
+        return self.stored_length() + query_length, 0

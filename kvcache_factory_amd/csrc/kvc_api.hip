@@ -459,22 +459,35 @@ __attribute__((visibility("default"))) int kvc_gather(const kvc_params* p, const
     return enqueue_gather(&g, nullptr, static_cast<hipStream_t>(hip_stream));
 }
 
-__attribute__((visibility("default"))) int kvc_decode_step(const kvc_decode_params* p, const void* q, const void* k_new, const void* v_new,
-                                                           const void* k_prefix, const void* v_prefix, void* k_tail, void* v_tail,
-                                                           void* out, void* hip_stream) {
+namespace {
+int decode_check(const kvc_decode_params* p, const kvc_decode_ext* x) {
     if (!p) return fail(KVC_ERR_INVALID, "params is NULL");
     if (p->dtype < KVC_BF16 || p->dtype > KVC_FP32) return fail(KVC_ERR_INVALID, "unknown dtype %d", p->dtype);
     if (p->bsz < 1 || p->n_q_heads < 1 || p->n_kv_heads < 1 || p->n_q_heads % p->n_kv_heads)
         return fail(KVC_ERR_INVALID, "bsz / head counts invalid");
     if (p->head_dim != 64 && p->head_dim != 128) return fail(KVC_ERR_UNSUPPORTED, "decode kernels are built for head_dim 64 and 128, got %d", p->head_dim);
     if (p->prefix_rows < 0 || p->tail_rows < 0 || p->new_rows < 1) return fail(KVC_ERR_INVALID, "row counts invalid");
-    if (!q || !k_new || !v_new || !k_tail || !v_tail || !out || (p->prefix_rows > 0 && (!k_prefix || !v_prefix)))
+    if (x) {
+        if (x->pruned_rows < 0) return fail(KVC_ERR_INVALID, "pruned_rows < 0");
+        if (x->pruned_rows > 0 && (x->pruned_dim < 1 || x->pruned_dim > p->head_dim || (x->pruned_dim * esize_of(p->dtype)) % 16))
+            return fail(KVC_ERR_INVALID, "pruned_dim must be 1..head_dim and a multiple of 16 bytes (pad the kept channels with zero columns), got %d", x->pruned_dim);
+    }
+    return KVC_OK;
+}
+int decode_run(const kvc_decode_params* p, const kvc_decode_ext* x, const void* q, const void* k_new, const void* v_new,
+               const void* k_prefix, const void* v_prefix, void* k_tail, void* v_tail, const void* k_pruned, const int16_t* chan,
+               void* out, void* workspace, size_t workspace_bytes, void* hip_stream) {
+    if (int rc = decode_check(p, x)) return rc;
+    const int pruned = x ? x->pruned_rows : 0;
+    if (!q || !k_new || !v_new || !k_tail || !v_tail || !out || (p->prefix_rows > 0 && !k_prefix) || (p->prefix_rows + pruned > 0 && !v_prefix))
         return fail(KVC_ERR_INVALID, "q, k_new, v_new, the tail, out (and the prefix when it has rows) must be non-NULL");
+    if (pruned > 0 && (!k_pruned || !chan)) return fail(KVC_ERR_INVALID, "pruned_rows > 0 needs k_pruned and chan");
     const int es = esize_of(p->dtype);
-    const void* ptrs[] = {q, k_new, v_new, k_prefix, v_prefix, k_tail, v_tail};
-    for (const void* x : ptrs) if (((uintptr_t)x) % 16) return fail(KVC_ERR_ALIGNMENT, "a pointer is not 16-byte aligned");
+    const void* ptrs[] = {q, k_new, v_new, k_prefix, v_prefix, k_tail, v_tail, pruned > 0 ? k_pruned : nullptr};
+    for (const void* ptr : ptrs) if (((uintptr_t)ptr) % 16) return fail(KVC_ERR_ALIGNMENT, "a pointer is not 16-byte aligned");
     const int64_t strides[] = {p->q_stride_b, p->q_stride_h, p->q_stride_l, p->new_stride_b, p->new_stride_h, p->new_stride_l,
-                               p->prefix_stride_b, p->prefix_stride_h, p->tail_stride_b, p->tail_stride_h};
+                               p->prefix_stride_b, p->prefix_stride_h, p->tail_stride_b, p->tail_stride_h,
+                               x ? x->v_prefix_stride_b : 0, x ? x->v_prefix_stride_h : 0, pruned > 0 ? x->pruned_stride_b : 0, pruned > 0 ? x->pruned_stride_h : 0};
     for (int64_t sd : strides) if ((sd * es) % 16) return fail(KVC_ERR_ALIGNMENT, "a stride is not a multiple of 16 bytes");
     kvc::DecodeArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -482,14 +495,49 @@ __attribute__((visibility("default"))) int kvc_decode_step(const kvc_decode_para
     a.q_stride_b = p->q_stride_b; a.q_stride_h = p->q_stride_h; a.q_stride_l = p->q_stride_l;
     a.new_stride_b = p->new_stride_b; a.new_stride_h = p->new_stride_h; a.new_stride_l = p->new_stride_l;
     a.prefix_stride_b = p->prefix_stride_b; a.prefix_stride_h = p->prefix_stride_h;
+    a.vprefix_stride_b = (x && x->v_prefix_stride_h) ? x->v_prefix_stride_b : p->prefix_stride_b;
+    a.vprefix_stride_h = (x && x->v_prefix_stride_h) ? x->v_prefix_stride_h : p->prefix_stride_h;
     a.tail_stride_b = p->tail_stride_b; a.tail_stride_h = p->tail_stride_h;
     a.out_stride_b = p->out_stride_b; a.out_stride_h = p->out_stride_h; a.out_stride_l = p->out_stride_l;
     a.bsz = p->bsz; a.n_q_heads = p->n_q_heads; a.n_kv_heads = p->n_kv_heads; a.group = p->n_q_heads / p->n_kv_heads;
     a.prefix_rows = p->prefix_rows; a.tail_rows = p->tail_rows; a.new_rows = p->new_rows;
     a.esize = es; a.row_bytes = p->head_dim * es; a.scaling = p->scaling;
+    if (pruned > 0) {
+        a.k_pruned = k_pruned; a.chan = chan; a.pruned_rows = pruned; a.pruned_dim = x->pruned_dim;
+        a.pruned_stride_b = x->pruned_stride_b; a.pruned_stride_h = x->pruned_stride_h;
+        a.chan_stride_b = x->chan_stride_b; a.chan_stride_h = x->chan_stride_h;
+    }
+    a.splits = 1;
+    if (workspace) {                                                  // as many splits as the workspace handed over can hold
+        const int rows = pruned + p->prefix_rows + p->tail_rows + p->new_rows;
+        int s = kvc::decode_splits(p->bsz, p->n_q_heads, p->new_rows, rows);
+        while (s > 1 && kvc::decode_part_bytes(p->bsz, p->n_q_heads, p->new_rows, p->head_dim, s) > workspace_bytes) --s;
+        if (((uintptr_t)workspace) % 16) return fail(KVC_ERR_ALIGNMENT, "workspace is not 16-byte aligned");
+        a.splits = s; a.part = static_cast<float*>(workspace);
+    }
     if (int rc = kvc::launch_decode_step(a, p->dtype, p->head_dim, static_cast<hipStream_t>(hip_stream)))
         return fail(rc, "no decode kernel for dtype %d head_dim %d", p->dtype, p->head_dim);
     return hip_ok("decode step launch");
+}
+}  // namespace
+
+__attribute__((visibility("default"))) int kvc_decode_step(const kvc_decode_params* p, const void* q, const void* k_new, const void* v_new,
+                                                           const void* k_prefix, const void* v_prefix, void* k_tail, void* v_tail,
+                                                           void* out, void* hip_stream) {
+    return decode_run(p, nullptr, q, k_new, v_new, k_prefix, v_prefix, k_tail, v_tail, nullptr, nullptr, out, nullptr, 0, hip_stream);
+}
+
+__attribute__((visibility("default"))) size_t kvc_decode_workspace_bytes(const kvc_decode_params* p, const kvc_decode_ext* ext) {
+    if (decode_check(p, ext)) return 0;
+    const int rows = (ext ? ext->pruned_rows : 0) + p->prefix_rows + p->tail_rows + p->new_rows;
+    return kvc::decode_part_bytes(p->bsz, p->n_q_heads, p->new_rows, p->head_dim, kvc::decode_splits(p->bsz, p->n_q_heads, p->new_rows, rows));
+}
+
+__attribute__((visibility("default"))) int kvc_decode_step2(const kvc_decode_params* p, const kvc_decode_ext* ext, const void* q, const void* k_new,
+                                                            const void* v_new, const void* k_prefix, const void* v_prefix, void* k_tail, void* v_tail,
+                                                            const void* k_pruned, const int16_t* chan, void* out, void* workspace,
+                                                            size_t workspace_bytes, void* hip_stream) {
+    return decode_run(p, ext, q, k_new, v_new, k_prefix, v_prefix, k_tail, v_tail, k_pruned, chan, out, workspace, workspace_bytes, hip_stream);
 }
 
 // ---- AdaKV / HeadKV -------------------------------------------------------------------------------------------------------
@@ -809,6 +857,14 @@ __attribute__((visibility("default"))) int kvc_ragged_decode_step(const kvc_ragg
     if (p->appended < 0 || p->new_rows < 1) return fail(KVC_ERR_INVALID, "row counts invalid");
     if (!q || !k_new || !v_new || !k_flat || !v_flat || !seg_off || !seg_len || !out) return fail(KVC_ERR_INVALID, "a pointer is NULL");
     const int es = esize_of(p->dtype);
+    {   // the kernels move 16-byte pieces, like kvc_decode_step's
+        const void* ptrs[] = {q, k_new, v_new, k_flat, v_flat};
+        for (const void* ptr : ptrs) if (((uintptr_t)ptr) % 16) return fail(KVC_ERR_ALIGNMENT, "a pointer is not 16-byte aligned");
+        const int64_t strides[] = {p->q_stride_b, p->q_stride_h, p->q_stride_l, p->new_stride_b, p->new_stride_h, p->new_stride_l};
+        for (int64_t sd : strides) if ((sd * es) % 16) return fail(KVC_ERR_ALIGNMENT, "a stride is not a multiple of 16 bytes");
+        if (p->slack_rows > 0 && p->appended + p->new_rows > p->slack_rows)
+            return fail(KVC_ERR_INVALID, "appended %d + new_rows %d exceed the %d spare rows behind every segment", p->appended, p->new_rows, p->slack_rows);
+    }
     kvc::RaggedDecodeArgs a;
     std::memset(&a, 0, sizeof(a));
     a.q = q; a.k_new = k_new; a.v_new = v_new; a.k_flat = k_flat; a.v_flat = v_flat; a.out = out; a.seg_off = seg_off; a.seg_len = seg_len;

@@ -151,6 +151,12 @@ struct DecodeArgs {        // one decode step over the compacted cache (kvc_deco
     int64_t out_stride_b, out_stride_h, out_stride_l;
     int bsz, n_q_heads, n_kv_heads, group, prefix_rows, tail_rows, new_rows, esize, row_bytes;
     float scaling;
+    // kvc_decode_step2: values with their own strides, ThinK's channel-pruned leading rows, rows split over workgroups
+    int64_t vprefix_stride_b, vprefix_stride_h;
+    const void* k_pruned; const int16_t* chan;        // [b][Hq][pruned_rows][pruned_dim], [b][Hq][pruned_dim]
+    int64_t pruned_stride_b, pruned_stride_h, chan_stride_b, chan_stride_h;
+    int pruned_rows, pruned_dim;
+    float* part; int splits, rows_per_split;          // workspace: (m, l, acc[D]) per (b, h, token, split)
 };
 
 // Raise a kernel's dynamic-LDS limit above 64 KB once per (kernel instantiation, device): `cache` is a function-local
@@ -175,7 +181,9 @@ size_t select_lds_bytes(int k);
 int launch_select_exact(const SelectArgs& a, int dtype, void* scratch, hipStream_t st);   // tie_mode torch_cpu
 size_t select_exact_scratch_bytes(int heads, int n, int k);     // per item
 int launch_gather(const GatherPair& p, hipStream_t st);
-int launch_decode_step(const DecodeArgs& a, int dtype, int head_dim, hipStream_t st);
+int launch_decode_step(DecodeArgs a, int dtype, int head_dim, hipStream_t st);
+int decode_splits(int bsz, int n_q_heads, int new_rows, int rows);
+size_t decode_part_bytes(int bsz, int n_q_heads, int new_rows, int head_dim, int splits);
 int launch_sort_prefix(const RaggedSortArgs& a, int dtype, void* scratch, hipStream_t st);
 int launch_l2norm(const L2NormArgs& a, int dtype, hipStream_t st);
 int launch_merge(const MergeArgs& a, int dtype, hipStream_t st);

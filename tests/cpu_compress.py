@@ -80,3 +80,27 @@ def oracle_think_prune(kc, q, recent_size, ratio, return_scores=False):
     """Stand-in for _kvc.think_prune (host-logic tests only)."""
     pruned, recent, keep, sc = O.think_prune(kc, q.contiguous(), recent_size, ratio)
     return (pruned, recent, keep, sc[None]) if return_scores else (pruned, recent, keep)
+
+
+def oracle_decode_step(q, k_new, v_new, k_prefix, v_prefix, prefix_rows, k_tail, v_tail, tail_rows, scaling, k_pruned=None, chan=None,
+                       pruned_rows=0):
+    """Stand-in for _kvc.decode_step (host-logic tests only): in-place tail append, then fp32 softmax attention over
+    [pruned rows (kept channels) | prefix rows | tail rows], token i of the step seeing tail rows < tail_rows + i + 1."""
+    b, hq, t, D = q.shape
+    g = hq // k_new.shape[1]
+    k_tail[:, :, tail_rows:tail_rows + t] = k_new
+    v_tail[:, :, tail_rows:tail_rows + t] = v_new
+    outs = []
+    for i in range(t):
+        T = tail_rows + i + 1
+        kt, vt = k_tail[:, :, :T].repeat_interleave(g, 1).float(), v_tail[:, :, :T].repeat_interleave(g, 1).float()
+        qi = q[:, :, i:i + 1].float()
+        parts = []
+        if pruned_rows:
+            qa = torch.gather(qi[:, :, 0], -1, chan.long().clamp(min=0)) * (chan >= 0)
+            parts.append(torch.einsum("bhd,bhrd->bhr", qa, k_pruned.float())[:, :, None])
+        parts.append(qi @ k_prefix[:, :, :prefix_rows].float().transpose(2, 3))
+        parts.append(qi @ kt.transpose(2, 3))
+        w = torch.softmax(torch.cat(parts, -1) * scaling, -1)
+        outs.append(w @ torch.cat([v_prefix[:, :, :pruned_rows + prefix_rows].float(), vt], 2))
+    return torch.cat(outs, 2).transpose(1, 2).to(q.dtype)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(kvc):
     lib = ctypes.CDLL(kvc.LIB_PATH)
     for s in syms:
         assert getattr(lib, s) is not None
-    assert kvc.lib().kvc_version() == 4
+    assert kvc.lib().kvc_version() == 5
 
 
 def test_params_struct_matches_header(kvc):

@@ -750,7 +750,8 @@ def test_patched_mistral_on_gpu(kvc, gpu_device):
 
 @pytest.mark.parametrize("dtype,D,hq,hkv,P,T,t", [(torch.bfloat16, 128, 32, 8, 128, 0, 1), (torch.bfloat16, 128, 32, 8, 128, 37, 1),
                                                   (torch.float16, 64, 8, 2, 40, 5, 3), (torch.float32, 128, 4, 4, 70, 9, 2),
-                                                  (torch.bfloat16, 128, 32, 8, 2056, 300, 1)])
+                                                  (torch.bfloat16, 128, 32, 8, 2056, 300, 1), (torch.bfloat16, 128, 32, 8, 2056, 1024, 2),
+                                                  (torch.float16, 128, 8, 8, 4104, 0, 1), (torch.bfloat16, 64, 4, 1, 63, 1, 1)])
 def test_decode_step_vs_reference_shaped_attention(kvc, gpu_device, dtype, D, hq, hkv, P, T, t):
     """kvc_decode_step (N1): append the step's K/V to the per-KV-head tail and attend over prefix + tail == SDPA over the
     reference-shaped cache cat(prefix, repeat_kv(tail + new)) (llama_model.py:287-289, 306-313), causal among the step's
@@ -775,6 +776,48 @@ def test_decode_step_vs_reference_shaped_attention(kvc, gpu_device, dtype, D, hq
     ref = torch.softmax(q.float() @ K.transpose(2, 3) * D ** -0.5 + mask, -1) @ V          # [1, hq, t, D]
     tol = {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10, torch.float32: 1e-5}[dtype]
     assert float((out.transpose(1, 2).float() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dtype,D,hq,hkv,P1,keep,Pr,T,t", [(torch.bfloat16, 128, 32, 8, 96, 77, 32, 0, 1), (torch.bfloat16, 128, 32, 8, 2016, 77, 32, 300, 1),
+                                                           (torch.float16, 64, 8, 2, 64, 45, 16, 5, 3), (torch.float32, 128, 4, 4, 50, 90, 20, 9, 2),
+                                                           (torch.bfloat16, 128, 8, 2, 40, 128, 8, 3, 1)])
+def test_think_decode_step_vs_fp32_attention(kvc, gpu_device, dtype, D, hq, hkv, P1, keep, Pr, T, t):
+    """SURVEY 8f N4, ThinK's decode step as ONE kvc_decode_step2 call (round 2: torch matmuls in the product path): the first P1
+    rows' keys hold only the `keep` kept channels (padded to 16 bytes, scored against the query's same channels), the recent Pr
+    rows and the per-KV-head tail are full-channel — against the reference's computation in fp32 (llama_model_think.py:175-196:
+    q[mask] @ key_pruned^T and q @ key^T, each / sqrt(D), cat, softmax, @ value) from the same inputs; tolerance as N1's."""
+    import cpu_compress
+    g = torch.Generator().manual_seed(P1 + T + keep)
+    rn = lambda *sh: torch.randn(*sh, generator=g).to(dtype)      # noqa: E731
+    q, kn, vn = rn(1, hq, t, D), rn(1, hkv, t, D), rn(1, hkv, t, D)
+    mask = torch.zeros(1, hq, D, dtype=torch.bool)
+    for h in range(hq):
+        mask[0, h, torch.randperm(D, generator=g)[:keep]] = True
+    kfull = rn(1, hq, P1, D)
+    key_pruned = kfull[mask.unsqueeze(2).expand(-1, -1, P1, -1)].view(1, hq, P1, keep)          # pyramidkv_utils.py:24-25
+    recent, values = rn(1, hq, Pr, D), rn(1, hq, P1 + Pr, D)
+    from kvcache_factory_amd.cache import ThinkDynamicLayer
+    layer = ThinkDynamicLayer()
+    layer.prefill_think(key_pruned.to(gpu_device), recent.to(gpu_device), mask.to(gpu_device), values.to(gpu_device), 1000)
+    layer._ktail = rn(1, hkv, T + t + 4, D).to(gpu_device); layer._vtail = rn(1, hkv, T + t + 4, D).to(gpu_device); layer._tail = T
+    kt0, vt0 = layer._ktail.clone().cpu(), layer._vtail.clone().cpu()
+    out = layer.attend(q.to(gpu_device), kn.to(gpu_device), vn.to(gpu_device), D ** -0.5)
+    assert out.shape == (1, t, hq, D) and layer._tail == T + t and layer.true_length == 1000 + t
+    assert torch.equal(layer._ktail[:, :, T:T + t].cpu(), kn) and torch.equal(layer._vtail[:, :, T:T + t].cpu(), vn)
+    # the reference's arithmetic in fp32: pruned part with the query's kept channels, full part, one softmax
+    grp = hq // hkv
+    ktail = torch.cat([kt0[:, :, :T], kn], 2).repeat_interleave(grp, 1).float(); vtail = torch.cat([vt0[:, :, :T], vn], 2).repeat_interleave(grp, 1).float()
+    qm = q[mask.unsqueeze(2).expand(-1, -1, t, -1)].view(1, hq, t, keep).float()
+    logits = torch.cat([qm @ key_pruned.float().transpose(2, 3) / D ** 0.5, q.float() @ torch.cat([recent.float(), ktail], 2).transpose(2, 3) / D ** 0.5], -1)
+    n = logits.shape[-1]
+    for i in range(t):
+        logits[:, :, i, n - t + i + 1:] = float("-inf")
+    ref = torch.softmax(logits, -1) @ torch.cat([values.float(), vtail], 2)
+    tol = {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10, torch.float32: 1e-5}[dtype]
+    assert float((out.transpose(1, 2).float().cpu() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+    # and the test-only CPU stand-in used by the plumbing tests computes the same thing
+    sh = cpu_compress.oracle_decode_step(q, kn, vn, recent, values, Pr, kt0.clone(), vt0.clone(), T, D ** -0.5, k_pruned=layer._kp.cpu(), chan=layer._chan.cpu(), pruned_rows=P1)
+    assert float((sh.transpose(1, 2).float() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
 
 
 @pytest.mark.parametrize("method", ["snapkv", "pyramidkv"])
@@ -811,9 +854,18 @@ def test_decode_logits_vs_oracle_built_cache(kvc, oracle, gpu_device, method, mo
                                             output_scores=True)
     finally:
         mp.replace_llama("fullkv")
-    assert torch.equal(outs["fused"].sequences, outs["oracle"].sequences)
-    for a, b in zip(outs["fused"].scores, outs["oracle"].scores):
-        assert float((a.float() - b.float()).abs().max()) <= 3e-2 * float(b.float().abs().max())
+    # step by step while both runs have seen the same tokens: logits within tolerance; should greedy decoding part ways, it may
+    # only be at a near tie (two bf16 attention kernels: the margin between the two candidates is within the same tolerance)
+    sa, sb = outs["fused"].sequences[0, ids.shape[1]:], outs["oracle"].sequences[0, ids.shape[1]:]
+    compared = 0
+    for i, (a, b) in enumerate(zip(outs["fused"].scores, outs["oracle"].scores)):
+        tol = 3e-2 * float(b.float().abs().max())
+        assert float((a.float() - b.float()).abs().max()) <= tol, (i, float((a.float() - b.float()).abs().max()), tol)
+        compared += 1
+        if int(sa[i]) != int(sb[i]):
+            assert abs(float(b[0, sa[i]]) - float(b[0, sb[i]])) <= tol, "tokens differ away from a tie"
+            break
+    assert compared >= 2
     for la, lb in zip(outs["fused"].past_key_values.layers, outs["oracle"].past_key_values.layers):
         assert la._split and not lb._split                               # (a) really took the split form, (b) the expanded one
         assert torch.equal(la._kbuf[:, :, :la._stored], lb._kbuf[:, :, :la._stored])      # same compressed prompt, byte for byte

@@ -8,7 +8,8 @@ import pytest
 import torch
 
 import golden_util as G
-from cpu_compress import oracle_compress, oracle_compress_batch, oracle_compress_merge, oracle_l2norm_compress, oracle_think_prune
+from cpu_compress import (oracle_compress, oracle_compress_batch, oracle_compress_merge, oracle_decode_step, oracle_l2norm_compress,
+                          oracle_think_prune)
 from kvcache_factory_amd import _kvc, monkeypatch as mp, pyramidkv_utils as pu
 
 
@@ -19,6 +20,7 @@ def cpu_backend(monkeypatch, oracle):
     monkeypatch.setattr(_kvc, "l2norm_compress", oracle_l2norm_compress)
     monkeypatch.setattr(_kvc, "compress_merge", oracle_compress_merge)
     monkeypatch.setattr(_kvc, "think_prune", oracle_think_prune)
+    monkeypatch.setattr(_kvc, "decode_step", oracle_decode_step)
     monkeypatch.setattr(pu, "BATCH_LAYERS", False)       # these tests watch one update_kv per layer
     yield
 
@@ -321,7 +323,10 @@ def test_batch_reordering_works_on_the_layers_own_buffers(cpu_backend):
     assert layer.get_seq_length() == 0 and layer.keys is None and layer.stored_length() == 0 and not layer.can_split()
     # ThinK's two-part cache reorders every part
     t = ThinkDynamicLayer()
-    t.prefill_think(torch.randn(3, 4, 6, 5, generator=g), k0, torch.rand(3, 4, 8, generator=g) > 0.4, v0, 50)
+    msk = torch.zeros(3, 4, 8, dtype=torch.bool)
+    msk[..., [0, 2, 3, 5, 7]] = True
+    t.prefill_think(torch.randn(3, 4, 6, 5, generator=g), k0, msk, torch.cat([v0[:, :, :6], v0], 2), 50)
+    assert t._chan[0, 0].tolist()[:5] == [0, 2, 3, 5, 7] and t._chan[0, 0, 5:].eq(-1).all() and t._kp.shape[-1] == t._chan.shape[-1]
     kp, m, kk = t.key_pruned.clone(), t.mask.clone(), t.keys.clone()
     t.reorder_cache(beam)
     assert torch.equal(t.key_pruned, kp[beam]) and torch.equal(t.mask, m[beam]) and torch.equal(t.keys, kk[beam])
