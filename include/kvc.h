@@ -262,6 +262,25 @@ typedef struct kvc_ragged_decode_params {
 int kvc_ragged_decode_step(const kvc_ragged_decode_params* p, const void* q, const void* k_new, const void* v_new,
                            void* k_flat, void* v_flat, const int64_t* seg_off, const int32_t* seg_len, void* out, void* hip_stream);
 
+/* ---- CAMKVCluster.update_kv (pyramidkv_utils.py:431-513), split at its random draw (ABI 5) --------------
+ * The reference scores like SnapKV without pooling (:461-476), then walks the tokens s = start_budget .. q_len - window - 1 in
+ * a Python loop (:487-502): merge_prob = colmean[s] / max(max(colmean[:start_budget]), max(colmean[s : s + window])) per head
+ * (colmean = torch.mean of the window rows' probabilities), NaN -> 0, inf -> 1, clamped to [0, 1];
+ * merge_mask = torch.bernoulli(merge_prob); value[s + 1 .. s + window] += value[s] * merge_mask / window, in place, in dtype
+ * arithmetic; finally top-k on the window sums and gather of the keys and of the MERGED values.  colmean does not depend on
+ * the merged values, so:
+ *   kvc_cam_plan   p->method = KVC_SNAPKV, p->pooling = KVC_POOL_NONE: scores_out [bsz*H_q][q_len - window] (the top-k input)
+ *                  and prob_out [bsz*H_q][q_len - window - start_budget] (dtype; token s at column s - start_budget);
+ *   (caller)       draws merge_mask = bernoulli(prob) — torch's CPU generator stream in the reference; any draw here;
+ *   kvc_cam_merge  v [bsz][H_q][q_len][head_dim] (strides p->v_stride_*, one copy per QUERY head: the masks differ per head),
+ *                  updated in place exactly as the loop does given merge_mask (uint8, same shape as prob_out);
+ *   kvc_select + kvc_gather (keys from k, values from the merged v) finish the job.
+ * start_budget = ceil(start_budget_ratio * q_len) (:479). */
+size_t kvc_cam_workspace_bytes(const kvc_params* p);
+int kvc_cam_plan(const kvc_params* p, const void* q, const void* k, int start_budget, void* scores_out, void* prob_out,
+                 void* workspace, size_t workspace_bytes, void* hip_stream);
+int kvc_cam_merge(const kvc_params* p, void* v, const uint8_t* merge_mask, int start_budget, void* hip_stream);
+
 /* ---- L2NormCluster.update_kv (pyramidkv_utils.py:394-429) ------------------------------------------
  * The k = max_capacity_prompt keys of every head with the SMALLEST L2 norm, in ascending norm order, and their values:
  *   token_norms = torch.norm(key_states, p=2, dim=-1)  (:419)  -> argsort ascending (:420) -> gather, first k rows (:423-427).

@@ -15,6 +15,7 @@ TIES_TORCH_CPU, TIES_CANONICAL = 0, 1
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_ALIGNMENT, ERR_HIP = 0, -1, -2, -3, -4, -5
 
 DTYPES = {torch.bfloat16: BF16, torch.float16: FP16, torch.float32: FP32}
+CAM = 100       # host-side method id (CAMKVCluster): no kvc_method of its own — kvc_cam_plan / kvc_cam_merge + select + gather
 POOLINGS = {"avgpool": POOL_AVG, "maxpool": POOL_MAX, None: POOL_NONE, "none": POOL_NONE}
 TIE_MODES = {"torch_cpu": TIES_TORCH_CPU, "canonical": TIES_CANONICAL}
 DOT_EXACT, DOT_MFMA16 = 0, 1
@@ -25,7 +26,8 @@ EXPORTS = ("kvc_version", "kvc_last_error", "kvc_workspace_bytes", "kvc_compress
            "kvc_gather", "kvc_pyramid_k", "kvc_workspace_layout", "kvc_workspace_bytes_batch", "kvc_compress_batch",
            "kvc_select_workspace_bytes", "kvc_decode_step", "kvc_ragged_workspace_bytes", "kvc_ragged_plan",
            "kvc_ragged_compact", "kvc_ragged_decode_step", "kvc_l2norm_workspace_bytes", "kvc_l2norm_compress",
-           "kvc_merge_workspace_bytes", "kvc_merge_pivot", "kvc_think_prune", "kvc_decode_workspace_bytes", "kvc_decode_step2")
+           "kvc_merge_workspace_bytes", "kvc_merge_pivot", "kvc_think_prune", "kvc_decode_workspace_bytes", "kvc_decode_step2",
+           "kvc_cam_workspace_bytes", "kvc_cam_plan", "kvc_cam_merge")
 
 
 class KvcError(RuntimeError):
@@ -97,6 +99,10 @@ def lib():
         L.kvc_workspace_bytes_batch.restype = sz
         L.kvc_compress_batch.argtypes = [pp, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         L.kvc_decode_step.argtypes = [ctypes.POINTER(DecodeParams)] + [vp] * 9
+        L.kvc_cam_workspace_bytes.argtypes = [pp]
+        L.kvc_cam_workspace_bytes.restype = sz
+        L.kvc_cam_plan.argtypes = [pp, vp, vp, ctypes.c_int, vp, vp, vp, sz, vp]
+        L.kvc_cam_merge.argtypes = [pp, vp, vp, ctypes.c_int, vp]
         L.kvc_decode_workspace_bytes.argtypes = [ctypes.POINTER(DecodeParams), ctypes.POINTER(DecodeExt)]
         L.kvc_decode_workspace_bytes.restype = sz
         L.kvc_decode_step2.argtypes = [ctypes.POINTER(DecodeParams), ctypes.POINTER(DecodeExt)] + [vp] * 11 + [sz, vp]
@@ -514,6 +520,33 @@ def l2norm_compress(k, v, rows, n_q_heads=None, return_indices=False, return_nor
     if return_norms:
         res.append(norms)
     return tuple(res)
+
+
+def cam_plan(q, k, window, start_budget):
+    """CAM (pyramidkv_utils.py:461-499) up to its draw: (window-sum scores [b, H_q, n], merge_prob [b, H_q, n - start_budget])."""
+    _require_gpu(q, k)
+    q, k = _last_dim_contig(q), _last_dim_contig(k)
+    dev = _one_device(q, k)
+    p = make_params(SNAPKV, q, k, None, window, 0, 1, None)
+    b, hq, L = q.shape[0], q.shape[1], q.shape[2]
+    sc = torch.empty(b, hq, L - window, dtype=q.dtype, device=dev)
+    prob = torch.empty(b, hq, L - window - start_budget, dtype=q.dtype, device=dev)
+    nbytes = lib().kvc_cam_workspace_bytes(ctypes.byref(p))
+    if nbytes == 0:
+        raise KvcError(ERR_INVALID, lib().kvc_last_error().decode())
+    ws = workspace(dev, nbytes)
+    _check(_call(dev, lib().kvc_cam_plan, ctypes.byref(p), _ptr(q), _ptr(k), int(start_budget), _ptr(sc), _ptr(prob), _ptr(ws), nbytes, _stream(dev)))
+    return sc, prob
+
+
+def cam_merge(v, merge_mask, window, start_budget):
+    """The CAM value recurrence (:500-501) in place on v [b, H_q, L, D] given merge_mask [b, H_q, L - window - start_budget] (0 / 1)."""
+    _require_gpu(v, merge_mask)
+    assert v.stride(3) == 1 and merge_mask.dtype == torch.uint8 and merge_mask.is_contiguous()
+    dev = _one_device(v, merge_mask)
+    p = make_params(SNAPKV, None, v, v, window, 0, 1, None)
+    _check(_call(dev, lib().kvc_cam_merge, ctypes.byref(p), _ptr(v), _ptr(merge_mask), int(start_budget), _stream(dev)))
+    return v
 
 
 def pyramid_k(cap, window, q_len, layer_idx, n_layers, beta=20):

@@ -33,6 +33,7 @@ _INIT = {
     "h2o": pu.init_H2O,
     "streamingllm": pu.init_StreamingLLM,
     "l2norm": pu.init_l2norm,
+    "cam": pu.init_CAM,
 }
 
 
@@ -103,6 +104,12 @@ def make_forward(method, apply_rotary_pos_emb, eager_attention_forward, repeat_k
                 pending.flush()                                              # layer: settle it before going on
             if layer.get_seq_length() == 0:                                  # prefill
                 q_len = key_states.shape[-2]
+                if method == "cam" and q_len >= self.kv_cluster.max_capacity_prompt:
+                    # CAM merges into the repeat_kv-expanded value_states IN PLACE (pyramidkv_utils.py:501) and the reference's
+                    # forward then attends over the merged values (llama_model.py:996-1010): same tensors, same order here
+                    key_states = repeat_kv(key_states, self.num_key_value_groups)
+                    value_states = repeat_kv(value_states, self.num_key_value_groups).contiguous()
+                    attn_module = _OneGroup(self)
                 taken = pu.BATCH_LAYERS and pending.add(
                     self.kv_cluster, key_states, query_states, value_states,
                     lambda kc, vc, layer=layer, q_len=q_len: layer.prefill(kc, vc, q_len), tag=layer,

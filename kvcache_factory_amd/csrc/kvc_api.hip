@@ -847,6 +847,63 @@ __attribute__((visibility("default"))) int kvc_think_prune(const kvc_think_param
     return hip_ok("think launch");
 }
 
+// ---- CAM (pyramidkv_utils.py:431-513), split at its random draw --------------------------------------------
+namespace {
+int cam_check(const kvc_params* p, int start_budget) {
+    if (int rc = validate(p, true)) return rc;
+    if (p->method != KVC_SNAPKV || p->pooling != KVC_POOL_NONE)
+        return fail(KVC_ERR_INVALID, "kvc_cam_*: method must be KVC_SNAPKV with KVC_POOL_NONE (CAM scores without pooling, :468-476)");
+    if (start_budget < 1 || start_budget + p->window >= p->q_len)
+        return fail(KVC_ERR_INVALID, "start_budget %d: the merge loop needs 1 <= start_budget and start_budget + window < q_len", start_budget);
+    return KVC_OK;
+}
+size_t cam_colmean_off(const Layout& l) { return align_up(l.total, 256); }
+}  // namespace
+
+__attribute__((visibility("default"))) size_t kvc_cam_workspace_bytes(const kvc_params* p) {
+    if (validate(p, true)) return 0;
+    const Layout l = carve(p);
+    return cam_colmean_off(l) + align_up((size_t)p->bsz * p->n_q_heads * p->q_len * esize_of(p->dtype), 256);
+}
+
+__attribute__((visibility("default"))) int kvc_cam_plan(const kvc_params* p, const void* q, const void* k, int start_budget, void* scores_out,
+                                                        void* prob_out, void* workspace, size_t workspace_bytes, void* hip_stream) {
+    if (int rc = cam_check(p, start_budget)) return rc;
+    if (!q || !k || !scores_out || !prob_out) return fail(KVC_ERR_INVALID, "q, k, scores_out and prob_out must be non-NULL");
+    const int es = esize_of(p->dtype);
+    if (int rc = check_strides("q", es, p->q_stride_b, p->q_stride_h, p->q_stride_l, q)) return rc;
+    if (int rc = check_strides("k", es, p->k_stride_b, p->k_stride_h, p->k_stride_l, k)) return rc;
+    const Layout l = carve(p);
+    if (!workspace || ((uintptr_t)workspace) % 256 || workspace_bytes < kvc_cam_workspace_bytes(p))
+        return fail(KVC_ERR_WORKSPACE, "workspace NULL, misaligned or smaller than kvc_cam_workspace_bytes");
+    char* ws = static_cast<char*>(workspace);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    Items it;
+    std::memset(&it, 0, sizeof(it));
+    it.n = 1; it.q[0] = q; it.k[0] = k; it.scores[0] = scores_out;
+    if (int rc = enqueue_scores(p, l, it, ws, st)) return rc;            // window-row sums, no pooling: the reference's attn_cache
+    kvc::CamArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.logits = ws + l.logits; a.rowmax = reinterpret_cast<const float*>(ws + l.rowmax); a.rowsum = reinterpret_cast<const float*>(ws + l.rowsum);
+    a.colmean = ws + cam_colmean_off(l); a.prob = prob_out;
+    a.bsz = p->bsz; a.n_q_heads = p->n_q_heads; a.q_len = p->q_len; a.window = p->window; a.start = start_budget;
+    if (int rc = kvc::launch_cam_prob(a, p->dtype, st)) return fail(rc, "no CAM kernel for dtype %d", p->dtype);
+    return hip_ok("cam plan launch");
+}
+
+__attribute__((visibility("default"))) int kvc_cam_merge(const kvc_params* p, void* v, const uint8_t* merge_mask, int start_budget, void* hip_stream) {
+    if (int rc = cam_check(p, start_budget)) return rc;
+    if (!v || !merge_mask) return fail(KVC_ERR_INVALID, "v and merge_mask must be non-NULL");
+    if (p->head_dim > 256) return fail(KVC_ERR_UNSUPPORTED, "head_dim > 256");
+    kvc::CamArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.v = v; a.mask = merge_mask;
+    a.v_stride_b = p->v_stride_b; a.v_stride_h = p->v_stride_h; a.v_stride_l = p->v_stride_l;
+    a.bsz = p->bsz; a.n_q_heads = p->n_q_heads; a.q_len = p->q_len; a.window = p->window; a.start = start_budget;
+    if (int rc = kvc::launch_cam_merge(a, p->dtype, p->head_dim, static_cast<hipStream_t>(hip_stream))) return fail(rc, "no CAM kernel for dtype %d", p->dtype);
+    return hip_ok("cam merge launch");
+}
+
 __attribute__((visibility("default"))) int kvc_ragged_decode_step(const kvc_ragged_decode_params* p, const void* q, const void* k_new,
                                                                   const void* v_new, void* k_flat, void* v_flat, const int64_t* seg_off,
                                                                   const int32_t* seg_len, void* out, void* hip_stream) {

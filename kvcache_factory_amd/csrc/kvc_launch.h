@@ -181,6 +181,16 @@ size_t select_lds_bytes(int k);
 int launch_select_exact(const SelectArgs& a, int dtype, void* scratch, hipStream_t st);   // tie_mode torch_cpu
 size_t select_exact_scratch_bytes(int heads, int n, int k);     // per item
 int launch_gather(const GatherPair& p, hipStream_t st);
+struct CamArgs {           // CAM (kvc_cam.hip)
+    const void* logits; const float* rowmax; const float* rowsum;      // the scoring stage's workspace regions
+    void* colmean;            // [b*Hq][L] dtype
+    void* prob;               // [b*Hq][L - W - start] dtype
+    void* v; const uint8_t* mask;                                       // merge: values in place, draws
+    int64_t v_stride_b, v_stride_h, v_stride_l;
+    int bsz, n_q_heads, q_len, window, start;
+};
+int launch_cam_prob(const CamArgs& a, int dtype, hipStream_t st);
+int launch_cam_merge(const CamArgs& a, int dtype, int head_dim, hipStream_t st);
 int launch_decode_step(DecodeArgs a, int dtype, int head_dim, hipStream_t st);
 int decode_splits(int bsz, int n_q_heads, int new_rows, int rows);
 size_t decode_part_bytes(int bsz, int n_q_heads, int new_rows, int head_dim, int splits);

@@ -2,16 +2,17 @@
 
 Call once BEFORE building the model, exactly like the reference (run_longbench.py:382-384); the per-layer knobs are
 then written onto `model.model.layers[i].self_attn.config.*` (run_longbench.py:253-261) and read by init_*.
-Methods in scope: "pyramidkv", "snapkv", "h2o", "streamingllm", "adakv", "headkv", (N4) "l2norm" and "think"
-(Llama only, like the reference, :80-83); "fullkv" leaves the model untouched (:86).  The reference's other method strings
-(cam, minference) are out of scope and raise.
+Methods in scope: "pyramidkv", "snapkv", "h2o", "streamingllm", "adakv", "headkv", (N4) "l2norm", "cam" and "think"
+(Llama only, like the reference, :80-83); "fullkv" leaves the model untouched (:86).  The reference's remaining method string
+(minference) is out of scope and raises.  (The reference's replace_mistral("cam") patches the LLAMA classes, monkeypatch.py:112-116 —
+a slip not reproduced: Mistral gets the CAM forward.)
 The reference also rebinds `prepare_inputs_for_generation` to reset `kv_seq_len` (llama_model.py:2598-2612); with
 transformers 5.x that bookkeeping lives in the cache layer (cache.CompressedDynamicLayer), so nothing else is patched.
 """
 import transformers
 
-_IN_SCOPE = ("pyramidkv", "snapkv", "h2o", "streamingllm", "adakv", "headkv", "l2norm", "think")
-_OUT_OF_SCOPE = ("cam", "minference")
+_IN_SCOPE = ("pyramidkv", "snapkv", "h2o", "streamingllm", "adakv", "headkv", "l2norm", "think", "cam")
+_OUT_OF_SCOPE = ("minference",)
 _ORIGINALS = {}
 
 

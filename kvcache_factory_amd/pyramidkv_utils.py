@@ -135,7 +135,7 @@ class PrefillBatch:
         alloc(bsz, n_heads, capacity_rows, head_dim, dtype, device) -> (k_buf, v_buf): optional owner-provided output
         buffers (a decode cache with spare rows); K' / V' are then written straight into them and sink gets views."""
         bsz, num_heads, q_len, head_dim = cluster._prefill_shapes(key_states, query_states)
-        if q_len < cluster.max_capacity_prompt or cluster._method in (_kvc.H2O, _kvc.L2NORM) or cluster.merge is not None:
+        if q_len < cluster.max_capacity_prompt or cluster._method in (_kvc.H2O, _kvc.L2NORM, _kvc.CAM) or cluster.merge is not None:
             return False                                             # (merge_kv takes the direct path: its own kernels)
         n_keep = cluster._budget(q_len)
         _say(f"{cluster._name} max_capacity_prompt {n_keep if cluster._method == _kvc.PYRAMIDKV else cluster.max_capacity_prompt}")
@@ -266,6 +266,46 @@ class PyramidKVCluster(_KVCluster):
 class H2OKVCluster(_KVCluster):
     """pyramidkv_utils.py:515-575: every query row scores; kernel_size / pooling are ignored (:555-561)."""
     _name, _method = "H2O", _kvc.H2O
+
+
+class CAMKVCluster(_KVCluster):
+    """pyramidkv_utils.py:431-513: SnapKV-style window scoring WITHOUT pooling (kernel_size / pooling are accepted
+    and ignored, :468-476), a stochastic merge of every token's value into its `window_size` successors (:487-502), then top-k
+    and gather of the keys and of the MERGED values.  On the GPU: kvc_cam_plan (scores + every token's merge probability — it
+    does not depend on the merged values), the draw, kvc_cam_merge (the in-place value recurrence, bit-exact given the draws),
+    kvc_select + kvc_gather.  `draw` is the reference's torch.bernoulli (:499) on the GPU: its random stream is not the CPU
+    generator's, so outputs equal the reference's GIVEN THE SAME DRAWS (tests substitute the reference's recorded ones).
+    Like the reference, value_states with H_q heads is merged IN PLACE (the caller's tensor; the reference's forward then
+    attends over it); an H_kv-head tensor is expanded first (the draws differ per query head)."""
+    _name, _method = "CAM", _kvc.CAM
+    draw = staticmethod(torch.bernoulli)
+
+    def __init__(self, start_budget_ratio=0.1, window_size=64, max_capacity_prompt=256 + 64, kernel_size=5, pooling='avgpool', merge=None):
+        self.reset(start_budget_ratio, window_size, max_capacity_prompt, kernel_size, pooling, merge)
+
+    def reset(self, start_budget_ratio=0.1, window_size=64, max_capacity_prompt=256 + 64, kernel_size=5, pooling='avgpool', merge=None):
+        super().reset(window_size, max_capacity_prompt, kernel_size, pooling, merge)
+        self.start_budget_ratio = start_budget_ratio
+
+    def update_kv(self, key_states, query_states, value_states, attention_mask, num_key_value_groups):
+        bsz, num_heads, q_len, head_dim = self._prefill_shapes(key_states, query_states)
+        _say(f"CAM max_capacity_prompt {self.max_capacity_prompt}")                         # :455
+        if q_len < self.max_capacity_prompt:                                                 # :457 pass-through, same objects
+            return key_states, value_states
+        W, n_keep = self.window_size, self.max_capacity_prompt - self.window_size
+        start = math.ceil(self.start_budget_ratio * q_len)                                   # :479
+        if value_states.shape[1] != num_heads:
+            value_states = value_states.repeat_interleave(num_heads // value_states.shape[1], dim=1)
+        elif value_states.stride(-1) != 1:
+            raise RuntimeError("CAM merges value_states in place: the last dimension must be contiguous")
+        if start + W < q_len:                                                                # the merge loop's range (:490) is not empty
+            sc, prob = _kvc.cam_plan(query_states, key_states, W, start)
+            mask = type(self).draw(prob.float()).to(torch.uint8).contiguous()
+            _kvc.cam_merge(value_states, mask, W, start)
+        else:
+            sc = _kvc.scores(_kvc.SNAPKV, query_states, key_states, W, 1, None)
+        idx = _kvc.select(sc, n_keep, TIE_MODE)
+        return _kvc.gather(key_states, idx, W, num_heads), _kvc.gather(value_states, idx, W, num_heads)
 
 
 class StreamingLLMKVCluster(_KVCluster):
@@ -416,6 +456,11 @@ def init_snapkv(self):
 def init_H2O(self):
     """pyramidkv_utils.py:990-1009 (default cap 2048)."""
     _init(self, H2OKVCluster, 2048)
+
+
+def init_CAM(self):
+    """pyramidkv_utils.py:970-988 (default cap 2048; the reference reads config.merge without a default, :987: None here)."""
+    _init(self, CAMKVCluster, 2048)
 
 
 def init_StreamingLLM(self):

@@ -251,6 +251,51 @@ def run_all_layers_case(c):
     return meta, out
 
 
+def run_cam_case(c):
+    """CAMKVCluster.update_kv (pyramidkv_utils.py:431-513).  The reference draws torch.bernoulli per token (:499); tapped here: the
+    probabilities it was handed and the outcomes it got ([H, n_tokens] each) are stored, so that the deterministic rest — scores,
+    the in-place value merge, top-k, gather — can be checked bit for bit GIVEN those draws.  value_states is mutated in place by
+    the reference: the SHA-256 of the mutated tensor is stored too."""
+    dtype = DT[c["dtype"]]
+    q, k, v = synth.make_qkv(c["Hq"], c["Hkv"], c["L"], c["D"], dtype, c["seed"], peaky=c.get("peaky", False), expanded=True)
+    v = v.clone()
+    cl = ref.CAMKVCluster(start_budget_ratio=c["start_ratio"], window_size=c["W"], max_capacity_prompt=c["cap"], kernel_size=c["kernel"],
+                          pooling=c["pooling"])
+    probs, draws = [], []
+    orig = torch.bernoulli
+
+    def tap(p, *a, **kw):
+        r = orig(p, *a, **kw)
+        probs.append(p.detach().clone()); draws.append(r.detach().clone())
+        return r
+    torch.bernoulli = tap
+    torch.manual_seed(c["seed"] + 1000)
+    try:
+        t0 = time.time()
+        with TopkTap() as tt, contextlib.redirect_stdout(io.StringIO()):
+            ko, vo = cl.update_kv(k, q, v, None, c["Hq"] // c["Hkv"])
+        dt = time.time() - t0
+    finally:
+        torch.bernoulli = orig
+    meta = dict(c)
+    meta["ref_seconds"] = round(dt, 4)
+    meta["passthrough"] = bool(ko is k)
+    meta["out_shape"] = list(ko.shape)
+    meta["k_out_sha256"], meta["v_out_sha256"], meta["merged_values_sha256"] = sha(ko), sha(vo), sha(v)
+    out = {}
+    if tt.calls:
+        sc, val, idx = tt.calls[0]
+        meta["n_keep"] = int(idx.shape[-1])
+        meta["start_budget"] = int(np.ceil(c["start_ratio"] * c["L"]))
+        meta["scores_sha256"] = sha(sc[0])
+        out["indices"] = idx[0].numpy().astype(np.int64)
+        out["prob"] = raw_bits(torch.stack(probs, dim=1))            # [H, n_tokens]
+        out["mask"] = torch.stack(draws, dim=1).float().numpy().astype(np.uint8)
+        if c["L"] <= 1100:
+            out["scores"] = raw_bits(sc[0])
+    return meta, out
+
+
 def make_cluster(c):
     kw = dict(window_size=c["W"], max_capacity_prompt=c["cap"], kernel_size=c["kernel"], pooling=c["pooling"])
     m = c["method"]
@@ -385,6 +430,13 @@ def cases():
     add("think_bf16_passthrough", method="think", dtype="bf16", Hq=4, Hkv=2, L=60, D=64, W=8, cap=128, kernel=7, pooling="maxpool", recent=32, ratio=0.4)
     add("think_8k_bf16", method="think", dtype="bf16", Hq=32, Hkv=8, L=8000, D=128, W=8, cap=128, kernel=7, pooling="maxpool", recent=32, ratio=0.4, seed=0)
     add("think_8k_bf16_cap2048", method="think", dtype="bf16", Hq=32, Hkv=8, L=8000, D=128, W=32, cap=2048, kernel=7, pooling="maxpool", recent=128, ratio=0.3, seed=0)
+    # ---- CAM (stochastic value merge; the reference's draws are recorded) ----
+    for dt in ("bf16", "fp16", "fp32"):
+        add(f"cam_{dt}_L300", method="cam", dtype=dt, Hq=8, Hkv=2, L=300, D=128, W=8, cap=72, kernel=5, pooling="avgpool", start_ratio=0.1)
+        add(f"cam_{dt}_W32_D64_L257", method="cam", dtype=dt, Hq=4, Hkv=4, L=257, D=64, W=32, cap=96, kernel=5, pooling="avgpool", start_ratio=0.1)
+    add("cam_bf16_passthrough", method="cam", dtype="bf16", Hq=4, Hkv=2, L=60, D=64, W=8, cap=128, kernel=5, pooling="avgpool", start_ratio=0.1)
+    add("cam_bf16_peaky_L1024", method="cam", dtype="bf16", Hq=8, Hkv=2, L=1024, D=128, W=8, cap=136, kernel=5, pooling="avgpool", start_ratio=0.1, peaky=True)
+    add("cam_2k_bf16", method="cam", dtype="bf16", Hq=32, Hkv=8, L=2000, D=128, W=8, cap=128, kernel=5, pooling="avgpool", start_ratio=0.1, seed=0)
     # ---- L2Norm (smallest key norms, ascending; no window, no query) ----
     for dt in ("bf16", "fp16", "fp32"):
         add(f"l2norm_{dt}_L600", method="l2norm", layer_idx=5, dtype=dt, Hq=8, Hkv=2, L=600, D=128, cap=96)
@@ -420,6 +472,8 @@ def main():
             meta, arrays = run_think_case(c)
         elif c["method"].startswith("merge_"):
             meta, arrays = run_merge_case(c)
+        elif c["method"] == "cam":
+            meta, arrays = run_cam_case(c)
         elif c["method"] == "pyramidkv_all_layers":
             meta, arrays = run_all_layers_case(c)
         else:

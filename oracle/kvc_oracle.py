@@ -276,3 +276,75 @@ def l2norm(k, v, max_capacity_prompt, n_q_heads, n_threads=0):
 def pyramid_k(cap, window, q_len, layer_idx, n_layers, beta=20):
     """A9 schedule (pyramidkv_utils.py:205-215): k for this layer, or -1 for pass-through."""
     return int(lib().kvco_pyramid_k(cap, window, q_len, layer_idx, n_layers, beta))
+
+
+# ---- SURVEY 8f N4: CAM (pyramidkv_utils.py:431-513), restated with explicit fp32 operations and dtype roundings ----------------
+def _rnd(x, dtype):
+    return x.to(dtype).float()
+
+
+def _cascade_sum(rows):
+    """fp32 sum of a list of tensors in the order of torch's multi_row_sum (SumKernel.cpp; kvc_oracle.cpp / kvc_common.h CascadeSum)."""
+    size, cl = len(rows), 0
+    while (1 << cl) < size:
+        cl += 1
+    level_power = max(4, cl // 4)
+    level_step = 1 << level_power
+    full = size - size % level_step
+    a0 = a1 = a2 = a3 = torch.zeros_like(rows[0])
+    i = in_step = 0
+    for v in rows:
+        a0 = a0 + v
+        i += 1
+        in_step += 1
+        if in_step == level_step and i <= full:
+            in_step, mask = 0, level_step - 1
+            a1, a0 = a1 + a0, torch.zeros_like(a0)
+            if (i & (mask << level_power)) == 0:
+                a2, a1 = a2 + a1, torch.zeros_like(a0)
+                if (i & (mask << (2 * level_power))) == 0:
+                    a3, a2 = a3 + a2, torch.zeros_like(a0)
+    return ((a0 + a1) + a2) + a3
+
+
+def cam_plan(q, k, window, start_budget, **modes):
+    """(window-sum scores [H, n] = the reference's attn_cache (:476), merge_prob [H, L - W - start] = what it hands to
+    torch.bernoulli at token s = start + column (:493-499)).  colmean = torch.mean(dim=-2) of the dtype probabilities: fp32 sum
+    of the W rows in torch's cascade order, / W, one rounding; merge_prob = colmean[s] / max(max(colmean[:start]), max(colmean[s:s+W])) in
+    dtype (fp32 quotient, one rounding), NaN -> 0, inf -> 1, clamp [0, 1]."""
+    sc, lg, pr, ws = scores(q, k, window, 1, "maxpool", want_intermediates=True, **modes)
+    dtype, (H, W, L) = q.dtype, pr.shape
+    cm = _rnd(_cascade_sum([pr[:, w].float() for w in range(W)]) / float(W), dtype)
+    m0 = cm[:, :start_budget].max(dim=-1).values
+    nT = L - window - start_budget
+    prob = torch.empty(H, nT)
+    for t in range(nT):
+        s = start_budget + t
+        mean_attn = torch.maximum(m0, cm[:, s:s + window].max(dim=-1).values)
+        prob[:, t] = _rnd(cm[:, s] / mean_attn, dtype)
+    prob[torch.isnan(prob)] = 0.0
+    prob[torch.isinf(prob)] = 1.0
+    return ws, prob.clamp(0.0, 1.0).to(dtype)
+
+
+def cam_merge(v, mask, window, start_budget):
+    """value[s + 1 .. s + W] += value[s] * merge_mask / W for s = start .. L - W - 1, in order, every operation rounded to the dtype
+    (:500-501).  v [1, H, L, D] (one copy per query head), mask [H, L - W - start] 0 / 1.  Returns the merged copy."""
+    dtype = v.dtype
+    out = v[0].float().clone()
+    H, L, D = out.shape
+    for t in range(L - window - start_budget):
+        s = start_budget + t
+        score1 = _rnd(_rnd(out[:, s] * mask[:, t, None].float(), dtype) / float(window), dtype)
+        out[:, s + 1:s + window + 1] = _rnd(out[:, s + 1:s + window + 1] + score1[:, None], dtype)
+    return out.to(dtype)[None]
+
+
+def cam(q, k, v, window, n_keep, start_budget, mask, **modes):
+    """CAMKVCluster.update_kv given the draws: (k_out, v_out, indices, scores, merge_prob, merged values)."""
+    g = q.shape[1] // v.shape[1]
+    vx = v.repeat_interleave(g, dim=1) if g > 1 else v
+    sc, prob = cam_plan(q, k, window, start_budget, **modes)
+    merged = cam_merge(vx, mask, window, start_budget)
+    idx, _ = topk(sc.contiguous(), n_keep, modes.get("tie_mode", TIES_TORCH)) if False else topk(sc.contiguous(), n_keep, TIES_TORCH)
+    return gather(k, idx, window, q.shape[1]), gather(merged, idx, window, q.shape[1]), idx, sc, prob, merged

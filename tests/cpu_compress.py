@@ -104,3 +104,23 @@ def oracle_decode_step(q, k_new, v_new, k_prefix, v_prefix, prefix_rows, k_tail,
         w = torch.softmax(torch.cat(parts, -1) * scaling, -1)
         outs.append(w @ torch.cat([v_prefix[:, :, :pruned_rows + prefix_rows].float(), vt], 2))
     return torch.cat(outs, 2).transpose(1, 2).to(q.dtype)
+
+
+def oracle_cam_plan(q, k, window, start_budget):
+    """Stand-ins for _kvc.cam_plan / cam_merge / select / gather (host-logic tests of CAMKVCluster only)."""
+    sc, prob = O.cam_plan(q.contiguous(), k.contiguous(), window, start_budget, dot_mode=O.DOT_CHAIN, sum_mode=O.SUM_TORCH16)
+    return sc[None], prob[None]
+
+
+def oracle_cam_merge(v, merge_mask, window, start_budget):
+    v.copy_(O.cam_merge(v, merge_mask[0], window, start_budget))
+    return v
+
+
+def oracle_select(scores_t, n_keep, tie_mode="torch_cpu"):
+    idx, _ = O.topk(scores_t[0].contiguous(), n_keep, O.TIES_TORCH if tie_mode in ("torch_cpu", 0) else O.TIES_CANON)
+    return idx[None]
+
+
+def oracle_gather(src, idx, window, n_q_heads):
+    return O.gather(src.contiguous(), idx[0], window, n_q_heads)

@@ -1396,3 +1396,34 @@ def test_random_shapes_n4_vs_oracle(kvc, oracle, gpu_device, case):
     kl_o, vl_o, il_o, nl_o = oracle.l2norm(k, v, rows, hq)
     assert torch.equal(G.bits(nl[0].cpu()), G.bits(nl_o)) and torch.equal(il[0].cpu(), il_o)
     assert torch.equal(G.bits(kl.cpu()), G.bits(kl_o)) and torch.equal(G.bits(vl.cpu()), G.bits(vl_o))
+
+
+@pytest.mark.parametrize("name", G.names(lambda m: m["method"] == "cam" and not m["passthrough"]))
+def test_cam_vs_reference_given_the_draws(kvc, oracle, gpu_device, name, monkeypatch):
+    """SURVEY 8f N4, CAM on the GPU (kvc_cam_plan / kvc_cam_merge + kvc_select + kvc_gather), split at the reference's random draw
+    (pyramidkv_utils.py:499): scores and every token's merge probability == the oracle bit for bit (0 ulp; the oracle is pinned
+    on the reference's recorded probabilities in tests/test_oracle_golden.py); GIVEN the reference's recorded draws the in-place
+    value merge equals the reference's mutated value_states (SHA-256, every dtype), and — bf16, where the scores are the
+    reference's bit for bit — CAMKVCluster.update_kv returns the reference's K' / V' bytes."""
+    from kvcache_factory_amd import pyramidkv_utils as pu
+    m, arr = G.MANIFEST[name], G.arrays(name)
+    q, k, v = G.inputs(m)
+    qd, kd = q.to(gpu_device), k[:, ::m["Hq"] // m["Hkv"]].contiguous().to(gpu_device)
+    sc, prob = kvc.cam_plan(qd, kd, m["W"], m["start_budget"])
+    sc_o, prob_o = oracle.cam_plan(q, k, m["W"], m["start_budget"], **G.product_modes(oracle, m))
+    assert torch.equal(G.bits(sc[0]), G.bits(sc_o)) and torch.equal(G.bits(prob[0]), G.bits(prob_o))
+    mask = torch.from_numpy(arr["mask"])
+    vd = v.clone().to(gpu_device)
+    kvc.cam_merge(vd, mask[None].contiguous().to(gpu_device), m["W"], m["start_budget"])
+    assert G.sha(vd) == m["merged_values_sha256"]
+    monkeypatch.setattr(pu.CAMKVCluster, "draw", staticmethod(lambda p: mask[None].float().to(gpu_device)))
+    cl = pu.CAMKVCluster(start_budget_ratio=m["start_ratio"], window_size=m["W"], max_capacity_prompt=m["cap"], kernel_size=m["kernel"], pooling=m["pooling"])
+    vv = v.clone().to(gpu_device)
+    ko, vo = cl.update_kv(kd, qd, vv, None, m["Hq"] // m["Hkv"])
+    assert G.sha(vv) == m["merged_values_sha256"]                            # merged in place, like the reference
+    if m["dtype"] == "bf16":
+        assert G.sha(ko) == m["k_out_sha256"] and G.sha(vo) == m["v_out_sha256"]
+    monkeypatch.undo()
+    torch.manual_seed(1)                                                     # the product's own draw (torch.bernoulli on the GPU)
+    ko2, vo2 = cl.update_kv(kd, qd, v.clone().to(gpu_device), None, m["Hq"] // m["Hkv"])
+    assert ko2.shape == ko.shape and torch.equal(ko2, ko)                    # keys do not depend on the draws

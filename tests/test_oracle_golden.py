@@ -272,3 +272,39 @@ def test_think_prune_against_reference(oracle, name):
     assert torch.equal(G.bits(sc), torch.from_numpy(a["channel_scores"]))
     assert torch.equal(keep[0], torch.from_numpy(a["keep"]).bool())
     assert G.sha(pruned) == m["pruned_sha256"] and G.sha(recent.contiguous()) == m["recent_sha256"]
+
+
+@pytest.mark.parametrize("name", G.names(lambda m: m["method"] == "cam" and not m["passthrough"]))
+def test_cam_given_the_references_draws(oracle, name):
+    """SURVEY 8f N4, CAM (pyramidkv_utils.py:431-513) split at its random draw: the oracle's window-sum scores and every token's
+    merge probability against what the reference handed to its .topk and to torch.bernoulli (bf16 / fp16: within the flip budget
+    of the other scored fixtures — at most max(2, 0.5 %) entries off by one unit in the last place; fp32: a few ulp, torch's
+    softmax exp is opaque); then, GIVEN the reference's recorded draws, the in-place value merge (SHA-256 of the mutated
+    value_states: exact in every dtype), the top-k on the reference's scores and the gathered K' / V' — bit for bit."""
+    m, arr = G.MANIFEST[name], G.arrays(name)
+    q, k, v = _inputs(m)
+    dt = G.DT[m["dtype"]]
+    sc, prob = oracle.cam_plan(q, k, m["W"], m["start_budget"], **G.product_modes(oracle, m))
+    ref_prob = G.from_bits(arr["prob"], dt)
+    mask = torch.from_numpy(arr["mask"])
+    d = G.ulp_diff(prob, ref_prob)
+    if m["dtype"] == "fp32":
+        assert int(d.max()) <= 64
+    else:
+        assert int(d.max()) <= 1 and int((d > 0).sum()) <= max(2, d.numel() // 200)
+        if "scores" in arr:
+            ds = G.ulp_diff(sc, G.from_bits(arr["scores"], dt))
+            assert int(ds.max()) <= 1 and int((ds > 0).sum()) <= max(2, ds.numel() // 200)
+    merged = oracle.cam_merge(v, mask, m["W"], m["start_budget"])
+    assert G.sha(merged) == m["merged_values_sha256"]                    # the recurrence is exact given the draws
+    ref_idx = torch.from_numpy(arr["indices"])
+    if "scores" in arr:                                                   # the selection on the reference's own scores
+        idx, _ = oracle.topk(G.from_bits(arr["scores"], dt).contiguous(), m["n_keep"], oracle.TIES_TORCH)
+        assert torch.equal(idx, ref_idx)
+    assert G.sha(oracle.gather(k, ref_idx, m["W"], m["Hq"])) == m["k_out_sha256"]
+    assert G.sha(oracle.gather(merged, ref_idx, m["W"], m["Hq"])) == m["v_out_sha256"]
+    if G.sha(sc) == m["scores_sha256"]:                                   # scores identical: the whole update_kv is
+        ko, vo, idx, _, _, _ = oracle.cam(q, k, v, m["W"], m["n_keep"], m["start_budget"], mask, **G.product_modes(oracle, m))
+        assert torch.equal(idx, ref_idx) and G.sha(ko) == m["k_out_sha256"] and G.sha(vo) == m["v_out_sha256"]
+    else:
+        assert m["dtype"] != "bf16", "every bf16 CAM fixture reproduces the reference's scores bit for bit"

@@ -8,8 +8,8 @@ import pytest
 import torch
 
 import golden_util as G
-from cpu_compress import (oracle_compress, oracle_compress_batch, oracle_compress_merge, oracle_decode_step, oracle_l2norm_compress,
-                          oracle_think_prune)
+from cpu_compress import (oracle_cam_merge, oracle_cam_plan, oracle_compress, oracle_compress_batch, oracle_compress_merge, oracle_decode_step,
+                          oracle_gather, oracle_l2norm_compress, oracle_select, oracle_think_prune)
 from kvcache_factory_amd import _kvc, monkeypatch as mp, pyramidkv_utils as pu
 
 
@@ -21,6 +21,8 @@ def cpu_backend(monkeypatch, oracle):
     monkeypatch.setattr(_kvc, "compress_merge", oracle_compress_merge)
     monkeypatch.setattr(_kvc, "think_prune", oracle_think_prune)
     monkeypatch.setattr(_kvc, "decode_step", oracle_decode_step)
+    for name, fn in (("cam_plan", oracle_cam_plan), ("cam_merge", oracle_cam_merge), ("select", oracle_select), ("gather", oracle_gather)):
+        monkeypatch.setattr(_kvc, name, fn)
     monkeypatch.setattr(pu, "BATCH_LAYERS", False)       # these tests watch one update_kv per layer
     yield
 
@@ -110,13 +112,13 @@ def test_replace_llama_and_mistral_rebind_and_restore():
     MA = transformers.models.mistral.modeling_mistral.MistralAttention
     orig_l, orig_m = LA.forward, MA.forward
     try:
-        for method in ("pyramidkv", "snapkv", "h2o", "streamingllm", "l2norm", "adakv", "headkv"):
+        for method in ("pyramidkv", "snapkv", "h2o", "streamingllm", "l2norm", "cam", "adakv", "headkv"):
             mp.replace_llama(method); mp.replace_mistral(method)
             assert LA.forward.kvc_method == method and MA.forward.kvc_method == method
         mp.replace_llama("no-such-method")               # unknown strings patch nothing (monkeypatch.py:19-87)
         assert LA.forward.kvc_method == "headkv"
         with pytest.raises(NotImplementedError):
-            mp.replace_llama("cam")
+            mp.replace_llama("minference")
     finally:
         mp.replace_llama("fullkv"); mp.replace_mistral("fullkv")
     assert LA.forward is orig_l and MA.forward is orig_m
@@ -596,5 +598,54 @@ def test_think_through_the_model(cpu_backend):
         assert torch.equal(seqs[("snapkv", None)], seqs[("think", 0.0)])
         with pytest.raises(NotImplementedError):
             mp.replace_mistral("think")
+    finally:
+        mp.replace_llama("fullkv")
+
+
+@pytest.mark.parametrize("name", ["cam_bf16_L300", "cam_fp16_W32_D64_L257", "cam_bf16_passthrough"])
+def test_cam_cluster_given_the_references_draws(cpu_backend, monkeypatch, name):
+    """CAMKVCluster.update_kv (pyramidkv_utils.py:431-513), init_CAM (:970-988): same constructor / signature; with the draw replaced
+    by the reference's recorded outcomes the returned K', V' and the IN-PLACE merged value_states are the reference's bytes; the
+    pass-through returns the same objects; H_kv-head values are expanded instead of merged in place."""
+    m, arr = G.MANIFEST[name], G.arrays(name)
+    q, k, v = G.inputs(m)
+    g = m["Hq"] // m["Hkv"]
+    cl = pu.CAMKVCluster(start_budget_ratio=m["start_ratio"], window_size=m["W"], max_capacity_prompt=m["cap"], kernel_size=m["kernel"], pooling=m["pooling"])
+    if m["passthrough"]:
+        ko, vo = cl.update_kv(k, q, v, None, g)
+        assert ko is k and vo is v
+        return
+    mask = torch.from_numpy(arr["mask"])[None].float()
+    monkeypatch.setattr(pu.CAMKVCluster, "draw", staticmethod(lambda prob: mask))
+    vv = v.clone()
+    ko, vo = cl.update_kv(k, q, vv, None, g)                              # expanded values: merged in place, like the reference
+    if m["dtype"] == "bf16":                                              # (fp16: a flipped score may move the selection, see the oracle test)
+        assert G.sha(ko) == m["k_out_sha256"] and G.sha(vo) == m["v_out_sha256"]
+    assert G.sha(vv) == m["merged_values_sha256"]
+    v_kv = v[:, ::g].contiguous()
+    ko2, vo2 = cl.update_kv(k[:, ::g].contiguous(), q, v_kv, None, g)     # GQA-native: same outputs, the caller's values untouched
+    assert torch.equal(ko2, ko) and torch.equal(vo2, vo) and torch.equal(v_kv, v[:, ::g])
+
+    class _Attn:
+        class config:
+            pass
+    at = _Attn()
+    at.config.merge = None
+    pu.init_CAM(at)
+    assert isinstance(at.kv_cluster, pu.CAMKVCluster) and at.config.max_capacity_prompt == 2048 and at.config.window_size == 32
+
+
+def test_cam_through_the_model(cpu_backend):
+    """replace_llama("cam") (monkeypatch.py:39-43): the prefill merges into the repeat_kv-expanded values and attends over them, the
+    compressed cache holds cap rows per head and decoding goes on at the true length."""
+    ids = torch.randint(0, 512, (1, 96))
+    try:
+        mp.replace_llama("cam")
+        model = _llama(layers=2)
+        _set_knobs(model, window_size=8, max_capacity_prompt=40, kernel_size=5, pooling="avgpool", merge=None)
+        torch.manual_seed(0)
+        out = _generate(model, ids, 3)
+        layer = out.past_key_values.layers[0]
+        assert out.sequences.shape[1] == 99 and layer.get_seq_length() == 98 and layer.keys.shape == (1, 32, 40 + 2, 128)
     finally:
         mp.replace_llama("fullkv")
