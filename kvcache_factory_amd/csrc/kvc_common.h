@@ -143,18 +143,32 @@ struct CascadeSum {
 };
 
 // ---- order-preserving integer keys for top-k (larger float -> larger key) ---------------------
+// NaN: torch's top-k / sort comparators put every NaN above every number and leave NaNs equal among themselves
+// (TopKImpl.h: (isnan(x) && !isnan(y)) || x > y).  All NaN patterns therefore share ONE key above +inf's — 0xfffe / 0xfffffffe,
+// one below the all-ones word that the lane-parallel heaps use as "no node" — and the key comparison is torch's comparator.
 template <int DT> struct Key;
 template <> struct Key<KVC_BF16> {
     static constexpr int bits = 16;
-    __device__ static __forceinline__ uint32_t of(uint16_t r) { return (r & 0x8000u) ? (uint32_t)(~r & 0xffffu) : (uint32_t)(r | 0x8000u); }
+    static constexpr uint32_t nan_above = 0x7f80u;        // |bits| beyond +inf's
+    __device__ static __forceinline__ uint32_t of(uint16_t r) {
+        const uint32_t k = (r & 0x8000u) ? (uint32_t)(~r & 0xffffu) : (uint32_t)(r | 0x8000u);
+        return (r & 0x7fffu) > nan_above ? 0xfffeu : k;
+    }
 };
 template <> struct Key<KVC_FP16> {
     static constexpr int bits = 16;
-    __device__ static __forceinline__ uint32_t of(uint16_t r) { return (r & 0x8000u) ? (uint32_t)(~r & 0xffffu) : (uint32_t)(r | 0x8000u); }
+    static constexpr uint32_t nan_above = 0x7c00u;
+    __device__ static __forceinline__ uint32_t of(uint16_t r) {
+        const uint32_t k = (r & 0x8000u) ? (uint32_t)(~r & 0xffffu) : (uint32_t)(r | 0x8000u);
+        return (r & 0x7fffu) > nan_above ? 0xfffeu : k;
+    }
 };
 template <> struct Key<KVC_FP32> {
     static constexpr int bits = 32;
-    __device__ static __forceinline__ uint32_t of(float f) { uint32_t u = f2u(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+    __device__ static __forceinline__ uint32_t of(float f) {
+        const uint32_t u = f2u(f), k = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        return (u & 0x7fffffffu) > 0x7f800000u ? 0xfffffffeu : k;
+    }
 };
 
 // Value held by lane (l ^ MASK), MASK in {1,2,4,8,16,32}: DPP quad_perm / row shifts and the gfx950 permlane swaps —

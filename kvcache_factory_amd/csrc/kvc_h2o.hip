@@ -15,6 +15,7 @@
 //                       cascade's own order (h2o_colpart_kernel / h2o_colcomb_kernel).
 // MFMA-bound by construction (2*Hq*L*L*D flops at the f32-MFMA rate); a bf16-MFMA variant is the planned
 // follow-up and cannot be bit-exact with the oracle (tools/mfma_probe.hip).
+#include <stdlib.h>
 #include "kvc_common.h"
 #include "kvc_launch.h"
 #include "kvc_ldsasm.h"
@@ -733,6 +734,7 @@ int h2o_chunk_rows(int heads, int L, int esize) {
     const size_t per256 = (size_t)heads * 256 * (size_t)L * esize;
     size_t rows = 256 * (kH2OSBudget / (per256 ? per256 : 1));
     if (rows < 512) rows = 512;
+    if (const char* e = getenv("KVC_H2O_CHUNK_ROWS")) { const long r = atol(e); if (r >= 256 && r % 256 == 0) rows = (size_t)r; }   // tuning aid
     return rows >= (size_t)L ? L : (int)rows;
 }
 

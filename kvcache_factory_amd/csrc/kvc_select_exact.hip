@@ -455,10 +455,17 @@ __device__ unsigned long long g_heap_stamps[8];
 constexpr int kSegKeys = 8192;
 constexpr size_t kWaveHeapLLds = (192 + 128) * 4 + (size_t)kSegKeys * 2;      // heap exchange area, one segment of keys
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+template <int DT>
 __device__ __forceinline__ uint32_t keys16x2(uint32_t x) {                     // Key<bf16 | fp16>::of on both halves
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     const s16x2 sg = __builtin_bit_cast(s16x2, x) >> (s16x2)15;                // v_pk_ashrrev_i16: 0xffff where negative
-    return x ^ ((__builtin_bit_cast(uint32_t, sg) & 0x7fff7fffu) | 0x80008000u);
+    const uint32_t k = x ^ ((__builtin_bit_cast(uint32_t, sg) & 0x7fff7fffu) | 0x80008000u);
+    // NaN halves -> 0xfffe (kvc_common.h): saturating |x| - threshold is non-zero exactly there
+    constexpr uint32_t thr = Key<DT>::nan_above * 0x10001u;
+    const u16x2 over = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, x & 0x7fff7fffu), __builtin_bit_cast(u16x2, thr));
+    const u16x2 one = __builtin_elementwise_min(over, (u16x2)1);
+    const uint32_t m = __builtin_bit_cast(uint32_t, (u16x2)(one * (u16x2)0xffff));
+    return (k & ~m) | (0xfffefffeu & m);
 }
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
@@ -486,7 +493,7 @@ __device__ __forceinline__ void partial_sort_waveL(const typename Dt<DT>::raw* s
     };
     auto land = [&](int u) {
         u32x4 x = r[u];
-        x.x = keys16x2(x.x); x.y = keys16x2(x.y); x.z = keys16x2(x.z); x.w = keys16x2(x.w);
+        x.x = keys16x2<DT>(x.x); x.y = keys16x2<DT>(x.y); x.z = keys16x2<DT>(x.z); x.w = keys16x2<DT>(x.w);
         reinterpret_cast<u32x4*>(seg)[u * 64 + lane] = x;
     };
     request(0);

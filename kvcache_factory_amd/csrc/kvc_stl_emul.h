@@ -4,6 +4,18 @@
 // (__heap_select, __move_median_to_first, __unguarded_partition(_pivot), __introselect, __insertion_sort,
 // __unguarded_linear_insert, __introsort_loop, __final_insertion_sort).  Compiles for the device (hipcc) and for the
 // host (g++, used by tests/test_stl_emul.py to check it against the real library on tie-heavy inputs).
+//
+// LICENCE NOTE.  This file follows the control flow of the GNU ISO C++ Library (libstdc++, Copyright (C) 2001-2021 Free Software
+// Foundation, Inc.; bits/stl_heap.h and bits/stl_algo.h also carry Copyright (c) 1994 Hewlett-Packard Company and Copyright (c)
+// 1996, 1997 Silicon Graphics Computer Systems, Inc. notices: "Permission to use, copy, modify, distribute and sell this software
+// and its documentation for any purpose is hereby granted without fee, provided that the above copyright notice appear in all copies
+// and that both that copyright notice and this permission notice appear in supporting documentation.  [The companies make] no
+// representations about the suitability of this software for any purpose.  It is provided "as is" without express or implied
+// warranty.").  libstdc++ is distributed under the GNU General Public License version 3, or (at your option) any later version,
+// with the GCC Runtime Library Exception version 3.1.  The algorithms are re-typed here, not copied, because the ORDER OF MOVES of
+// these routines is the specification of torch-CPU's tie order; whoever redistributes this file should treat it as a derived work
+// of those headers under the same terms (GPL-3.0-or-later WITH GCC-exception-3.1) — see NOTICE at the repository root.  Nothing
+// else in the repository derives from libstdc++ sources.
 #pragma once
 #include <stdint.h>
 
@@ -29,7 +41,8 @@ inline u64 uni(u64 v) { return v; }
 inline int uni(int v) { return v; }
 #endif
 
-// comp(a, b): a sorts before b  <=>  value(a) > value(b)   (NaN-free scores; keys are order-preserving)
+// comp(a, b): a sorts before b  <=>  value(a) > value(b)   (keys are order-preserving; every NaN has the one key above +inf's,
+// kvc_common.h Key<>: the key comparison IS torch's NaN-first comparator)
 KVC_HD inline bool comp(u64 a, u64 b) { return (uint32_t)(a >> 32) > (uint32_t)(b >> 32); }
 
 struct Arr {                 // random-access view of the (key<<32 | index) array, LDS or global

@@ -1427,3 +1427,26 @@ def test_cam_vs_reference_given_the_draws(kvc, oracle, gpu_device, name, monkeyp
     torch.manual_seed(1)                                                     # the product's own draw (torch.bernoulli on the GPU)
     ko2, vo2 = cl.update_kv(kd, qd, v.clone().to(gpu_device), None, m["Hq"] // m["Hkv"])
     assert ko2.shape == ko.shape and torch.equal(ko2, ko)                    # keys do not depend on the draws
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("n,k", [(7992, 120), (7992, 17), (2000, 500), (640, 10), (640, 11), (70000, 64)])
+def test_nan_scores_order_like_torch(kvc, gpu_device, dtype, n, k):
+    """torch's top-k comparator puts every NaN above every number and leaves NaNs equal among themselves (TopKImpl.h, reached
+    from pyramidkv_utils.py:334).  Round 2 assumed NaN-free scores; now all NaN patterns (either sign, any payload) share the one
+    key above +inf's, so the exact-tie select returns torch-CPU topk's indices on rows WITH NaNs too — checked against torch
+    itself (CPU topk on the same bits), both libstdc++ regimes, packed and 64-bit nodes, -inf / +inf present."""
+    g = torch.Generator().manual_seed(n + k)
+    sc = (torch.rand(4, n, generator=g) * 0.01).to(dtype)
+    bits = sc.view(torch.int32 if dtype == torch.float32 else torch.int16)
+    nan_pos, nan_neg = {torch.bfloat16: (0x7fc0, -64), torch.float16: (0x7e00, -512), torch.float32: (0x7fc00000, -4194304)}[dtype]
+    for h in range(4):
+        where = torch.randperm(n, generator=g)[: (0, 3, 40, k + 5)[h]]           # none, a few, some, more NaNs than the budget
+        bits[h, where[::2]] = nan_pos
+        bits[h, where[1::2]] = nan_neg                                            # negative-sign NaN patterns too
+        sc[h, torch.randperm(n, generator=g)[:2]] = float("inf")
+        sc[h, torch.randperm(n, generator=g)[:2]] = float("-inf")
+    want = torch.topk(sc, k, dim=-1).indices
+    assert bool(torch.isnan(torch.gather(sc.float(), 1, want)[3]).all())          # torch: NaNs first
+    got = kvc.select(sc[None].contiguous().to(gpu_device), k, "torch_cpu")[0].cpu()
+    assert torch.equal(got, want)
