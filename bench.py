@@ -32,6 +32,7 @@ from kvcache_factory_amd import _kvc, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured float4-copy rate
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md); the exact H2O kernel runs the f32-input MFMA (157 TF)
+MFMA_F32_PEAK_TFLOPS = 157.3 # f32-input MFMA (v_mfma_f32_32x32x2_f32: 64 cycles per SIMD, 256 CUs x 4 SIMDs at 2.4 GHz): the exact dot mode's pipe
 HQ, HKV, D, LAYERS = 32, 8, 128, 32
 
 CONFIGS = {
@@ -208,7 +209,7 @@ def kernel_breakdown(prompt, dev, tie_mode, reps=10):
     return out
 
 
-def pmc_traffic(kernel_prefix, tag="r02"):
+def pmc_traffic(kernel_prefix, tag="r03"):
     """HBM bytes per launch of one kernel from the committed PMC passes (profiles/<tag>_pmc_batch_*.csv; separate
     rocprofv3 --pmc runs of tools/prof_driver.py; FETCH_SIZE doubled per the gfx950 correction).  None if absent."""
     import csv
@@ -426,8 +427,15 @@ def main():
                      "kscan_algorithmic_bytes_per_launch": scan_b * LAYERS, "kscan_achieved_GBs": scan_b * LAYERS / t_scan / 1e9,
                      "kscan_frac": scan_b * LAYERS / t_scan / 1e9 / HBM_PEAK_GBS,
                      "kscan_traffic": pmc_traffic("kvc::logits_kernel"),
-                     "kscan_traffic_source": "profiles/r02_pmc_batch_{FETCH,WRITE}_SIZE.csv (separate rocprofv3 --pmc passes of "
+                     "kscan_traffic_source": "profiles/r03_pmc_batch_{FETCH,WRITE}_SIZE.csv (separate rocprofv3 --pmc passes of "
                                              "tools/prof_driver.py; FETCH_SIZE x2 gfx950 correction; includes the logits it writes)"}
+            if a.dot_mode == "exact":
+                # the exact dot mode computes the d-ascending fp32 fmaf chain on the f32-input MFMA, which runs at the fp32 VALU
+                # rate: with 32 FLOP per K byte that pipe, not HBM, bounds the K scan — both fractions reported
+                fl = 2.0 * HQ * cfg["W"] * cfg["L"] * D * LAYERS
+                kscan.update({"kscan_mfma_f32_TFLOPs": fl / t_scan / 1e12, "kscan_mfma_f32_peak_TFLOPs": MFMA_F32_PEAK_TFLOPS,
+                              "kscan_mfma_f32_frac": fl / t_scan / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                              "kscan_binding_limit": "f32-input MFMA (exact fmaf-chain dot products); HBM in dot_mode mfma16"})
             if dom == "logits_kernel":
                 out["roofline"] = {"bound": "hbm", "kernel": kscan["kscan_kernel"], "achieved": kscan["kscan_achieved_GBs"],
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kscan["kscan_frac"], "traffic": kscan["kscan_traffic"],
@@ -436,7 +444,7 @@ def main():
                                    "time_share": kt[dom] / tot}
             else:
                 t_dom = kt[dom]
-                out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": sel_b * LAYERS / t_dom / 1e9, "peak": HBM_PEAK_GBS,
+                out["roofline"] = {"bound": "latency" if dom.startswith("select_exact") else "hbm", "kernel": dom, "achieved": sel_b * LAYERS / t_dom / 1e9, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": sel_b * LAYERS / t_dom / 1e9 / HBM_PEAK_GBS,
                                    "traffic": pmc_traffic("kvc::select"), "launch_us": t_dom * 1e6,
                                    "algorithmic_bytes_per_launch": sel_b * LAYERS, "time_share": t_dom / tot,

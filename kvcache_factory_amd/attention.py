@@ -192,6 +192,8 @@ def make_ragged_forward(method, apply_rotary_pos_emb, eager_attention_forward, r
             if layer.get_seq_length() == 0:                                  # prefill (:2322)
                 self.kv_cluster.update_kv(key_states, query_states, value_states, slack=pu.RAGGED_SLACK)
                 layer.prefill(self.kv_cluster.ragged, key_states.shape[-2])    # ("not compress", :696: every head keeps all rows)
+                self.kv_cluster.ragged = None      # the layer owns the flattened cache now: the module keeps only the small metadata
+                                                   # (the cluster lives as long as the model; it would pin the last prompt's cache)
             else:                                                            # decode (:2363-2390)
                 attn_output = layer.decode_attend(query_states, key_states, value_states, self.scaling)
                 return self.o_proj(attn_output.reshape(*input_shape, -1)), None

@@ -359,6 +359,9 @@ class _RaggedCluster:
         self.cu_offset = self.cu_headlens = None
         self.ragged = None
 
+    # head_lens / cu_klen / max_seqlen_k / klen_sum are the PREFILL's values (:684-699).  The reference advances them per decode step
+    # for its flash_attn_varlen call (llama_model.py:2371-2374); here the decode step reads seg_len + appended from the cache layer
+    # (RaggedDynamicLayer), so they are not advanced.
     def _init_metadata(self, num_heads, k_lens, device):                       # :684-699
         i32 = dict(dtype=torch.int32, device=device)
         self.head_lens = torch.tensor(k_lens, **i32)

@@ -34,4 +34,11 @@ for cfgname in c2 c2_w32 c3; do
     python3 $R/tools/pmc_summary.py /tmp/pmc_$n $OUT/${TAG}_pmc_batch_${suffix}$n.csv > /dev/null
   done
 done
+# 4. round 3: decode step (N1 / N3 / ThinK) and the N2 prototype under the kernel trace, the one-wave probes behind WaveHeapL
+if [ "${2:-all}" != "nopmc" ]; then :; fi
+rm -rf /tmp/kt_dec && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_dec -- python3 $R/tools/decode_timing.py > $OUT/${TAG}_decode_timing.log 2>&1
+grep "kvc::\|^\"Name\|attention\|fmha\|Cijk\|cat\|index" /tmp/kt_dec/*/*_kernel_stats.csv | head -40 > $OUT/${TAG}_kernel_stats_decode_timing.csv
+rm -rf /tmp/kt_n2 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_n2 -- python3 $R/tools/n2_probe.py > $OUT/${TAG}_n2_probe.log 2>&1
+head -25 /tmp/kt_n2/*/*_kernel_stats.csv > $OUT/${TAG}_n2_kernel_stats.csv
+(cd $R/tools && for p in hop_probe step_probe; do [ -x ./$p ] && ./$p > $OUT/${TAG}_$p.txt 2>&1; done; [ -x ./heap_probe ] && ./heap_probe 7992 120 260 > $OUT/${TAG}_heap_probe.txt 2>&1)
 ls -la $OUT
