@@ -659,6 +659,18 @@ struct ArrT {                // the view kvc_stl_emul.h's routines take, on an a
     __device__ __forceinline__ void set(int i, u64 v) const { NodeIO<AP>::st(p, i, v); }
     __device__ __forceinline__ void swap(int i, int j) const { const u64 a = get(i), b = get(j); set(i, b); set(j, a); }
 };
+// A store for the lanes of `mask` only, WITHOUT a branch: the compiler turns `if (pred) p[i] = v` into s_and_saveexec +
+// s_cbranch_execz, and a branch costs a lone wave ~40 cycles whether taken or not (tools/step_probe.hip).  exec is put back
+// inside the same statement.  (Loads need none of this: an index clamped into range makes them unconditional — the compiler
+// serialises PREDICATED loads, one memory round trip each, which is what made the partition scan slow in round 2.)
+__device__ __forceinline__ void store_lanes(lds_u16* p, int v, u64 mask) {
+    u64 keep;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(keep) : "s"(mask), "v"((uint32_t)(uintptr_t)p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_lanes(glb_int* p, int v, u64 mask) {
+    u64 keep;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dword %2, %3, off\n\ts_mov_b64 exec, %0" : "=&s"(keep) : "s"(mask), "v"(p), "v"(v) : "memory");
+}
 template <class AP>
 struct WaveSel {
     typedef ArrT<AP> Arr;
@@ -683,18 +695,18 @@ struct WaveSel {
         for (int base = first; base < last; base += 64 * UF) {
             uint32_t kx[UF];
 #pragma unroll
-            for (int u = 0; u < UF; ++u) { const int i = base + u * 64 + lane; kx[u] = i < last ? IO::key(arr, i) : 0u; }
+            for (int u = 0; u < UF; ++u) { const int i = base + u * 64 + lane; kx[u] = IO::key(arr, i < last ? i : last - 1); }   // unconditional
 #pragma unroll
             for (int u = 0; u < UF; ++u) {
                 const int i = base + u * 64 + lane;
                 const bool sl = i < last && !(kx[u] > pk), sr = i < last && !(pk > kx[u]);
                 const u64 ml = __ballot(sl), mr = __ballot(sr);
                 const int rank = NL + __builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0));
-                if (sl && rank < cap) Lp[rank] = (i - first);
+                store_lanes(Lp + rank, i - first, __ballot(sl && rank < cap));
                 NL += __builtin_popcountll(ml);
                 int slot = nrm + __builtin_amdgcn_mbcnt_hi((uint32_t)(mr >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mr, 0));
                 if (slot >= ring) slot -= ring;
-                if (sr) Rr[slot] = (i - first);
+                store_lanes(Rr + slot, i - first, mr);
                 const int c = __builtin_popcountll(mr);
                 NR += c;
                 nrm += c;
@@ -713,19 +725,23 @@ struct WaveSel {
     // (a random read and a random write each) are skipped.
     template <class LT, int US, bool LEFT_ONLY>
     __device__ __forceinline__ void swap_pairs(int first, int T, const LT* Lp, const LT* Rr, int nrm, int ring) {
+        // lanes beyond the last pair repeat pair T - 1: they load what its lane loads and store what it stores (every load of an
+        // iteration precedes its stores) — no predicate, no branch, no serialised loads
         for (int t0 = 0; t0 < T; t0 += 64 * US) {
             int l[US], r[US];
             u64 av[US], bv[US];
 #pragma unroll
             for (int u = 0; u < US; ++u) {
-                const int t = t0 + u * 64 + lane;
-                l[u] = t < T ? first + (int)Lp[t] : -1;
-                r[u] = t < T ? first + r_at(Rr, nrm, ring, t) : -1;
+                int t = t0 + u * 64 + lane;
+                t = t < T ? t : T - 1;
+                l[u] = first + (int)Lp[t];
+                r[u] = first + r_at(Rr, nrm, ring, t);
             }
 #pragma unroll
-            for (int u = 0; u < US; ++u) if (l[u] >= 0) { if (!LEFT_ONLY) av[u] = IO::ld(arr, l[u]); bv[u] = IO::ld(arr, r[u]); }
+            for (int u = 0; u < US; ++u) { if (!LEFT_ONLY) av[u] = IO::ld(arr, l[u]); bv[u] = IO::ld(arr, r[u]); }
+            asm volatile("" ::: "memory");
 #pragma unroll
-            for (int u = 0; u < US; ++u) if (l[u] >= 0) { IO::st(arr, l[u], bv[u]); if (!LEFT_ONLY) IO::st(arr, r[u], av[u]); }
+            for (int u = 0; u < US; ++u) { IO::st(arr, l[u], bv[u]); if (!LEFT_ONLY) IO::st(arr, r[u], av[u]); }
         }
     }
     template <class LT, bool LEFT_ONLY>
@@ -757,8 +773,8 @@ struct WaveSel {
             int lo_t = 0, hi_t = lim;                                     // answer in [lo_t, hi_t]
             while (hi_t - lo_t > 0) {
                 const int span = hi_t - lo_t, step = (span + 63) / 64;    // probe t = lo_t + lane * step
-                const int t = lo_t + lane * step;
-                const bool ok = t < hi_t && (int)Lp[t] < r_at(Rr, nrm, ring, t);
+                const int t = lo_t + lane * step, tc = t < hi_t ? t : hi_t - 1;                   // (clamped: unconditional loads)
+                const bool ok = t < hi_t && (int)Lp[tc] < r_at(Rr, nrm, ring, tc);
                 const u64 okm = __ballot(ok);
                 const int good = __builtin_popcountll(okm);               // probes 0 .. good-1 hold (prefix property)
                 if (good == 0) { hi_t = lo_t; break; }

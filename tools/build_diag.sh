@@ -14,7 +14,7 @@ B=$(mktemp -d)
 cd "$R/kvcache_factory_amd/csrc"
 FLAGS=$(make -s --eval 'pf:
 	@echo $(HIPFLAGS)' pf)
-for f in kvc_api kvc_score kvc_select kvc_select_exact kvc_gather kvc_h2o kvc_decode kvc_ragged kvc_l2norm kvc_merge kvc_think; do
+for f in kvc_api kvc_score kvc_select kvc_select_exact kvc_gather kvc_h2o kvc_decode kvc_ragged kvc_l2norm kvc_merge kvc_think kvc_cam; do
   /opt/rocm/bin/hipcc $FLAGS $FLAG -c $f.hip -o $B/$f.o &
 done
 wait
