@@ -217,7 +217,7 @@ kvc::GatherArgs gather_args(const kvc_params* p, const Items& it, int which, boo
 }
 
 // A7 for every item (+ A8 in the same kernel when `fuse`).  exact_scratch: n_items regions for the exact tie mode.
-int enqueue_select(const kvc_params* p, const Items& it, bool fuse, void* exact_scratch, hipStream_t st) {
+int enqueue_select(const kvc_params* p, const Items& it, bool fuse, void* exact_scratch, hipStream_t st, bool members_only = false) {
     const int n_sel = p->q_len - p->window;
     if (p->tie_mode == KVC_TIES_CANONICAL) {
         if (it.k_max > 16384) return fail(KVC_ERR_UNSUPPORTED, "tie_mode canonical: k=%d > 16384 (the LDS sort of the selected set) not built", it.k_max);
@@ -233,6 +233,7 @@ int enqueue_select(const kvc_params* p, const Items& it, bool fuse, void* exact_
     s.pow2 = 1;
     while (s.pow2 < s.k_max) s.pow2 <<= 1;
     if (fuse) { s.fuse = 1; s.gk = gather_args(p, it, 0, true); s.gv = gather_args(p, it, 1, true); }
+    s.members_only = members_only ? 1 : 0;
     if (p->tie_mode == KVC_TIES_TORCH_CPU) {
 #if defined(KVC_STAMPS)
         if (p->debug_stage_mask & 32) s.fuse = 2;            // diag build: phase stamps over the index output (no gather follows)
@@ -630,7 +631,9 @@ __attribute__((visibility("default"))) int kvc_ragged_plan(const kvc_params* p, 
             Items sel;
             std::memset(&sel, 0, sizeof(sel));
             sel.n = 1; sel.scores[0] = ws + r.flat; sel.idx[0] = reinterpret_cast<int64_t*>(ws + r.top); sel.keep[0] = (int)k_tot; sel.k_max = (int)k_tot;
-            if (int rc = enqueue_select(&ps, sel, false, ws + r.sel, st)) return rc;
+            // (only WHICH elements torch's top-(H*base) holds matters here, not their order: the final __sort_heap — a fifth of the
+            // walk — is skipped)
+            if (int rc = enqueue_select(&ps, sel, false, ws + r.sel, st, true)) return rc;
             kvc::launch_ragged_recount(a, p->bsz, reinterpret_cast<const int64_t*>(ws + r.top), st);
         } else if (int rc = kvc::launch_ragged_plan(a, p->dtype, p->bsz, st)) {
             return fail(rc, "ragged plan launch failed");

@@ -70,6 +70,7 @@ struct SelectArgs {
     int n_items;
     int pow2;              // next power of two >= k_max
     int fuse;              // 1: also gather K (gk) and V (gv) rows of the head in the same workgroup
+    int members_only;      // exact mode, large partial_sort heaps: the caller needs the selected SET only (AdaKV's per-head counts)
     GatherArgs gk, gv;
 };
 

@@ -1342,7 +1342,7 @@ __global__ __launch_bounds__(64) void select_exact_kernel(const SelectArgs a, u6
 #pragma unroll
             for (int j = 0; j < U; ++j) cur[j] = nxt[j];
         }
-        sort_heap_(H, 0, k);
+        if (!a.members_only) sort_heap_(H, 0, k);                     // (the heap's content IS the selection; only its order needs the pops)
         __syncthreads();
         for (int t = lane; t < k; t += 64) out[t] = (int64_t)(lds_arr[t] & 0xffffffffull);
     } else {
