@@ -102,7 +102,8 @@ typedef struct kvc_params {
                                   as many as fit in 1 GiB (identical results).  Bit8 (measurement): the softmax stage reloads the
                                   logits in its second pass instead of keeping the exponentials in registers (identical results).
                                   Bit9 (measurement): G * W == 128 query rows per KV head scanned by the one-M-tile-at-a-time
-                                  kernel instead of the four-waves-share-a-tile one (identical results). */
+                                  kernel instead of the four-waves-share-a-tile one (identical results).  Bit10 (measurement): at window 8 the
+                                  one-workgroup-per-head softmax stage without its chain-wave / worker-wave split (identical results). */
     int32_t dot_mode;          /* kvc_dot_mode */
     int64_t q_stride_b, q_stride_h, q_stride_l;   /* element strides of q[b][h][l][:] */
     int64_t k_stride_b, k_stride_h, k_stride_l;

@@ -264,11 +264,12 @@ def compress(method, q, k, v, window, n_keep, kernel_size=5, pooling="avgpool", 
 def scores(method, q, k, window, kernel_size=5, pooling="avgpool", want_intermediates=False, dot_mode=None,
            softmax_path=None, debug_mask=0):
     """Stage A1-A5 only.  Returns pooled scores [bsz,Hq,L-W] (+ logits [bsz,Hq,L,W], rowmax, rowsum).
-    softmax_path: None (library's choice) | "split" | "fused" — identical results (debug_stage_mask bits 3/4)."""
+    softmax_path: None (library's choice) | "split" | "fused" | "fused_r2" (the fused form without the chain / worker wave split) —
+    identical results (debug_stage_mask bits 3 / 4 / 10)."""
     _require_gpu(q, k)
     q, k = _last_dim_contig(q), _last_dim_contig(k)
     p = make_params(method, q, k, None, window, 0, kernel_size, pooling, dot_mode=dot_mode)
-    p.debug_stage_mask = {None: 0, "split": 8, "fused": 16}[softmax_path] | debug_mask
+    p.debug_stage_mask = {None: 0, "split": 8, "fused": 16, "fused_r2": 16 | 1024}[softmax_path] | debug_mask
     bsz, hq, L = q.shape[0], q.shape[1], q.shape[2]
     sc = torch.empty(bsz, hq, L - window, dtype=q.dtype, device=q.device)
     nbytes = lib().kvc_workspace_bytes(ctypes.byref(p))

@@ -1327,6 +1327,148 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
 }
 
 // ---------------------------------------------------------------------------------------------
+// softmax_pool_ws_kernel (round 3, W = 8, rows up to 8 064 keys): the same arithmetic in the same order as
+// softmax_pool_kernel, with the workgroup's two jobs on DIFFERENT waves.  In softmax_pool_kernel the 128 threads that add
+// the torch-order chains (16 chains x 8 rows) also own keys: their two waves alternate between a stage's 64 dependent
+// adds and the next stage's exponentials while the other fourteen waves wait at the barrier (tools/softmax_stamps.py:
+// 12.3 of a workgroup's 23.6 us are the 8 stages).  Here waves 0-1 only add chains and waves 2-15 (896 = 56 x 16 threads)
+// own the keys: a stage's chain adds run beside the next stage's exponentials.  Stage boundaries stay multiples of 16
+// keys, so chain c still sums the keys = c (mod 16) in ascending order — bit-identical row sums
+// (test_softmax_pool_forms_identical).  Measured: 97 -> 92 us per 32-layer C2 launch; what bounds the stage is the
+// exponentials (14 instructions each, a dependent v_pk_fma chain at four waves per SIMD: 6 cycles per instruction) —
+// computing all of a thread's exponentials before the first stage, for more independent chains, was measured and is
+// slower (99 us: the chain waves then idle through that phase).
+// grid = (bsz*n_q_heads, items), block = 1024.  LDS as softmax_pool_kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int WS_CHAIN = 128, WS_WORK = SP_THREADS - WS_CHAIN, WS_ITERS = 9;     // 9 x 896 = 8 064 keys
+template <int DT>
+__global__ __launch_bounds__(SP_THREADS) void softmax_pool_ws_kernel(const ScoreArgs a) {
+    const ScoreView vw = view_of(a, blockIdx.y);
+    typedef typename Dt<DT>::raw raw;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int W = 8;
+    const int tid = threadIdx.x, hb = blockIdx.x;
+    const bool worker = tid >= WS_CHAIN;
+    const int wt = tid - WS_CHAIN;
+    const int L = a.q_len, n = L - W;
+    const int iters = (L + WS_WORK - 1) / WS_WORK;
+    float* const m = reinterpret_cast<float*>(smem);              // [64]
+    float* const rinv = m + 64;                                   // [64]
+    float* const scratch = rinv + 64;                             // [256]
+    float* const stage = scratch + 256;                           // [2][ESTAGE] (pass 1)
+    float* const seg = stage;                                     // [<= 8064]   (pass 2)
+    const raw* const lg = reinterpret_cast<const raw*>(vw.logits) + (int64_t)hb * L * W;
+    constexpr int VPK = (W * (int)sizeof(raw)) / 16;
+    uint4 rawx[WS_ITERS][VPK];
+#pragma unroll
+    for (int it = 0; it < WS_ITERS; ++it) {
+        const int key = it * WS_WORK + wt;
+#pragma unroll
+        for (int c = 0; c < VPK; ++c)
+            rawx[it][c] = (worker && it < iters && key < L) ? reinterpret_cast<const uint4*>(lg + (int64_t)key * W)[c] : make_uint4(0, 0, 0, 0);
+    }
+    block_row_max(vw.pmax + (int64_t)hb * a.n_tiles * W, a.n_tiles, W, m, scratch);
+    float mr[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) mr[w] = m[w];
+    // pass 1: the workers' exponentials (kept in registers) go to LDS stage by stage; the chain waves add them in torch's order
+    float e[WS_ITERS][W];
+    const int cw = tid >> 4, cl = tid & 15;                       // chain threads: row cw, chain cl
+    float acc = 0.0f;
+#pragma unroll
+    for (int it = 0; it < WS_ITERS; ++it) {
+        if (it < iters) {                                          // (uniform)
+            const int key = it * WS_WORK + wt;
+            float x[W];
+            widen_logits<DT, W>(rawx[it], x);
+#pragma unroll
+            for (int w = 0; w < W; w += 2) {
+                const f32x2 ex = exp_u20x2(f32x2{x[w], x[w + 1]} - f32x2{mr[w], mr[w + 1]});
+                e[it][w] = (worker && key < L) ? ex.x : 0.0f; e[it][w + 1] = (worker && key < L) ? ex.y : 0.0f;
+            }
+            float* buf = stage + (it & 1) * ESTAGE;
+            if (worker) {
+#pragma unroll
+                for (int r = 0; r < W; ++r) buf[r * EPITCH + wt] = e[it][r];
+            }
+            __syncthreads();       // stage `it` is complete; the chain waves finished stage it - 1 before they arrived here, so
+                                   // the workers may overwrite that buffer's twin (stage it + 1) while stage `it` is being added
+            if (!worker) {
+                const float* row = buf + cw * EPITCH + cl;
+                const int cnt = (L - it * WS_WORK - cl + 15) >> 4;     // keys it * 896 + cl + 16 i < L
+                if (cnt >= WS_WORK / 16) {
+                    float va[8], vb[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) va[i] = row[16 * i];
+#pragma unroll
+                    for (int b = 0; b < WS_WORK / 16 / 8; ++b) {       // 7 blocks of 8 terms, the next block's reads in flight
+                        float (&cur)[8] = (b & 1) ? vb : va;
+                        float (&nxt)[8] = (b & 1) ? va : vb;
+                        if (b + 1 < WS_WORK / 16 / 8) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) nxt[i] = row[16 * (8 * (b + 1) + i)];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc = acc + cur[i];
+                    }
+                } else {
+                    for (int i = 0; i < cnt; ++i) acc = acc + row[16 * i];
+                }
+            }
+        }
+    }
+    const float sum = chain16_fold(acc);
+    if (!worker && cl == 0) {
+        rinv[cw] = 1.0f / sum;
+        vw.rowmax[(int64_t)hb * W + cw] = m[cw];
+        vw.rowsum[(int64_t)hb * W + cw] = sum;
+    }
+    __syncthreads();                                              // rinv visible; the stages are free for the per-key sums
+    float ri[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) ri[w] = rinv[w];
+    // pass 2: p = round(e / sum), window sum (cascade), round -> LDS; then pooling by all 1024 threads
+#pragma unroll
+    for (int it = 0; it < WS_ITERS; ++it) {
+        if (it < iters && worker) {
+            const int key = it * WS_WORK + wt;
+            if (key < L) {
+                CascadeSum cs;
+                cs.init(W);
+#pragma unroll
+                for (int w = 0; w < W; w += 2) {
+                    const f32x2 pr = f32x2{e[it][w], e[it][w + 1]} * f32x2{ri[w], ri[w + 1]};
+                    cs.add(rnd<DT>(pr.x));
+                    cs.add(rnd<DT>(pr.y));
+                }
+                seg[key] = key < n ? rnd<DT>(a.window_mean ? cs.result() / (float)W : cs.result()) : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    const int pad = a.pooling == KVC_POOL_NONE ? 0 : a.kernel_size / 2;
+    raw* const out = reinterpret_cast<raw*>(vw.scores) + (int64_t)hb * n;
+    for (int jo = tid; jo < n; jo += SP_THREADS) {
+        float c;
+        if (a.pooling == KVC_POOL_NONE) {
+            c = seg[jo];
+        } else {
+            const int lo = jo - pad < 0 ? 0 : jo - pad;
+            const int hi = jo - pad + a.kernel_size > n ? n : jo - pad + a.kernel_size;
+            if (a.pooling == KVC_POOL_MAX) {
+                c = -__builtin_inff();
+                for (int i = lo; i < hi; ++i) { const float v = seg[i]; c = v > c ? v : c; }
+            } else {
+                float s2 = 0.0f;
+                for (int i = lo; i < hi; ++i) s2 = s2 + seg[i];
+                c = rnd<DT>(s2 / (float)a.kernel_size);
+            }
+        }
+        out[jo] = Dt<DT>::st(c);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host launch
 // ---------------------------------------------------------------------------------------------
 // One workgroup per head (softmax_pool_kernel) when there are enough heads x items to fill the chip (a prompt's layers
@@ -1348,6 +1490,14 @@ static void launch_softmax_pool_t(const ScoreArgs& a, hipStream_t st) {
         if (fused) {
             if (!(m & 6)) return;
             dim3 g((unsigned)(a.bsz * a.n_q_heads), (unsigned)a.n_items);
+            if constexpr (WV == 8) {                          // chain waves beside worker waves (debug_stage_mask bit 10: round 2's form)
+                if (a.q_len >= 1024 && a.q_len <= WS_ITERS * WS_WORK && !(a.stage_mask & (256 | 1024))) {
+                    static LdsCache c_ws = {};
+                    (void)ensure_lds(reinterpret_cast<const void*>(&softmax_pool_ws_kernel<DT>), kSoftmaxLds, c_ws);
+                    hipLaunchKernelGGL((softmax_pool_ws_kernel<DT>), g, dim3(SP_THREADS), kSoftmaxLds, st, a);
+                    return;
+                }
+            }
             constexpr int KEEP = 64 / WV;                     // iterations whose exponentials stay in registers
             static LdsCache c_keep = {}, c_loop = {};
             if (KEEP >= 2 && iters <= KEEP && !(a.stage_mask & 256)) {

@@ -420,9 +420,10 @@ def test_softmax_pool_forms_identical(kvc, gpu_device, name):
     m = G.MANIFEST[name]
     qd, kd, _ = G.inputs(m, device=gpu_device, expanded=False)
     a = kvc.scores(kvc.SNAPKV, qd, kd, m["W"], m["kernel"], m["pooling"], want_intermediates=True, softmax_path="split")
-    b = kvc.scores(kvc.SNAPKV, qd, kd, m["W"], m["kernel"], m["pooling"], want_intermediates=True, softmax_path="fused")
-    assert torch.equal(G.bits(a[0]), G.bits(b[0]))
-    assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32)) and torch.equal(a[3].view(torch.int32), b[3].view(torch.int32))
+    for path in ("fused", "fused_r2"):       # at W = 8 and 1 024 <= L <= 8 064 "fused" is the chain-wave / worker-wave kernel of round 3
+        b = kvc.scores(kvc.SNAPKV, qd, kd, m["W"], m["kernel"], m["pooling"], want_intermediates=True, softmax_path=path)
+        assert torch.equal(G.bits(a[0]), G.bits(b[0]))
+        assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32)) and torch.equal(a[3].view(torch.int32), b[3].view(torch.int32))
 
 
 def _tie_heavy_scores(heads, n, dtype, seed, levels):
