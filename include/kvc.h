@@ -103,7 +103,9 @@ typedef struct kvc_params {
                                   logits in its second pass instead of keeping the exponentials in registers (identical results).
                                   Bit9 (measurement): G * W == 128 query rows per KV head scanned by the one-M-tile-at-a-time
                                   kernel instead of the four-waves-share-a-tile one (identical results).  Bit10 (measurement): at window 8 the
-                                  one-workgroup-per-head softmax stage without its chain-wave / worker-wave split (identical results). */
+                                  one-workgroup-per-head softmax stage without its chain-wave / worker-wave split (identical results).
+                                  Bit11 (H2O exact mode, testing): round 2's kernels that write the logit matrix to the
+                                  workspace instead of the fused one that keeps 16 query rows of it in registers (identical results). */
     int32_t dot_mode;          /* kvc_dot_mode */
     int64_t q_stride_b, q_stride_h, q_stride_l;   /* element strides of q[b][h][l][:] */
     int64_t k_stride_b, k_stride_h, k_stride_l;

@@ -103,7 +103,10 @@ Layout carve(const kvc_params* p, int n_items = 1) {
         l.h2o_rows = (p->method == KVC_H2O && !h2o_fast) ? kvc::h2o_chunk_rows((int)heads, (int)L, (int)es) : 0;
         if (l.h2o_rows > 512 && (p->debug_stage_mask & 128)) l.h2o_rows = 512;      // testing aid: several chunks at small L
         // logits: [h][L][W] for the window methods; H2O exact: the chunk [h][h2o_rows][L]; H2O fast: nothing
-        l.logits = off; off = align_up(off + (p->method == KVC_H2O ? heads * (size_t)l.h2o_rows * L * es : heads * L * R * es), 256);
+        // (H2O exact, fused form: the same region holds the permuted copy of K, [bsz * Hkv][L][D])
+        const size_t h2o_kt = (size_t)p->bsz * p->n_kv_heads * L * p->head_dim * es;
+        const size_t h2o_s = heads * (size_t)l.h2o_rows * L * es;
+        l.logits = off; off = align_up(off + (p->method == KVC_H2O ? (h2o_fast ? 0 : (h2o_s > h2o_kt ? h2o_s : h2o_kt)) : heads * L * R * es), 256);
         l.pmax = off;   off = align_up(off + (p->method == KVC_H2O ? 0 : heads * (size_t)l.n_tiles * W * 4), 256);
         // H2O: column sums of every 256-row block (+ one slot for the leftover rows), fp32, columns padded to even
         l.psum = off;   off = align_up(off + ((p->method == KVC_H2O && !h2o_fast) ? heads * (size_t)(l.n_chunks + 1) * ((n + 1) & ~(size_t)1) * 4 : 0), 256);
@@ -152,6 +155,8 @@ int enqueue_scores(const kvc_params* p, const Layout& l, const Items& it, char* 
             h.S = w + l.logits;
             h.row0 = 0; h.rows = p->q_len; h.s_rows = l.h2o_rows;
             h.fast = l.h2o_rows == 0 ? 1 : 0;
+            h.kt = w + l.logits;
+            h.legacy = (p->debug_stage_mask & 2048) ? 1 : 0;
             h.rowmax = reinterpret_cast<float*>(w + l.rowmax);
             h.rinv = reinterpret_cast<float*>(w + l.rowsum);
             h.part = reinterpret_cast<float*>(w + l.psum);

@@ -727,6 +727,240 @@ __global__ __launch_bounds__(FAST_THREADS, 2) void h2o_fast_colsum_kernel(const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fused exact mode (round 3; 16-bit dtypes, 16 <= L <= 8192): the logits never leave the compute unit.
+//   One workgroup (16 waves) = one 256-row block of one head, walked in sub-blocks of 16 query rows — the unit of torch's
+//   column cascade (16 rows into a0, a0 into a1).  The 16 x L logits of a sub-block live in REGISTERS, packed two per
+//   dword (256 KB of the CU's 512 KB at L = 8192), so every later phase re-reads registers instead of HBM:
+//     A  S = round(round(q.k) / sqrt(D)) (+ window mask) on v_mfma_f32_16x16x4_f32 — a k-ordered fmaf chain like the
+//        32x32x2 form (tools/mfma16x4_probe.hip: 0 of 51 200 results differ from the chain).  Key tile T = 16 i + wave;
+//        Q is the A operand (fp32 in LDS, re-read per step), K the B operand straight from a pre-permuted copy
+//        (h2o_kperm_kernel: lane (key, g) needs dims g, g + 4, ...; there they are 64 contiguous bytes), row maxima kept;
+//     B  row maxima across the waves (LDS);
+//     C  exponentials by all waves into an LDS ring, two tiles per barrier; waves 0-3 add them in torch's order: chain c
+//        of row r = keys = c (mod 16) ascending = lane c of the MFMA layout, tile after tile; then the xor butterfly;
+//     D  p = round(exp * rinv); the 16 rows of a key are summed IN ROW ORDER by four chained MFMAs with A = 1
+//        (fma(1, p, acc) = acc + p: the Q rows are dealt to the MFMA's row slots so that register v of lane group g is
+//        row 4 v + g, which makes MFMA v add rows 4 v .. 4 v + 3 in order); a1 += a0 per sub-block.
+//   Output: the block's a1 (and the leftover a0) in `part`, combined by h2o_colcomb*_kernel as before.
+//   HBM traffic: Q and K once (K re-streamed from L2: the workgroup ids of one XCD walk one KV head, fast_map).
+// ---------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x32 __attribute__((ext_vector_type(32)));
+constexpr int FZ_WAVES = 16, FZ_THREADS = 64 * FZ_WAVES, FZ_TPW = 32, FZ_MAX_L = 16 * FZ_WAVES * FZ_TPW;   // 8192 keys
+constexpr int FZ_EBUF = 32 * 4 * 64;                         // floats per ring half: 32 tile slots x 4 registers x 64 lanes
+
+// Kt[b][g][key][gq * (D/4) + s] = K[b][g][key][4 s + gq].  grid = (ceil(L * D / 8 / 256), bsz * n_kv_heads), block = 256.
+template <int DT, int D>
+__global__ __launch_bounds__(256) void h2o_kperm_kernel(const H2OArgs a) {
+    typedef typename Dt<DT>::raw raw;
+    constexpr int NS = D / 4, CPR = D / 8;
+    const int L = a.q_len, bg = blockIdx.y, b = bg / a.n_kv_heads, g = bg % a.n_kv_heads;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= L * CPR) return;
+    const int key = c / CPR, p0 = (c % CPR) * 8, gq = p0 / NS, s0 = p0 % NS;
+    const raw* kr = reinterpret_cast<const raw*>(a.k) + (int64_t)b * a.k_stride_b + (int64_t)g * a.k_stride_h + (int64_t)key * a.k_stride_l;
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        w[e] = (uint32_t)kr[4 * (s0 + 2 * e) + gq] | ((uint32_t)kr[4 * (s0 + 2 * e + 1) + gq] << 16);
+    reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.kt) + ((int64_t)bg * L + key) * (D * 2))[c % CPR] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <int DT> __device__ __forceinline__ float wide_lo(uint32_t w) {
+    if constexpr (DT == KVC_BF16) return u2f(w << 16); else return Dt<DT>::ld((uint16_t)(w & 0xffffu));
+}
+template <int DT> __device__ __forceinline__ float wide_hi(uint32_t w) {
+    if constexpr (DT == KVC_BF16) return u2f(w & 0xffff0000u); else return Dt<DT>::ld((uint16_t)(w >> 16));
+}
+
+// grid = bsz * n_q_heads * ceil(L / 256), block = 1024.  LDS: Q operand [16][D + 4] f32, maxima [16][16], rinv [16], ring 2 x FZ_EBUF, a1 [8192].
+template <int DT, int D>
+__global__ __launch_bounds__(FZ_THREADS) void h2o_fused_kernel(const H2OArgs a) {
+    typedef typename Dt<DT>::raw raw;
+    constexpr int NS = D / 4, KV4 = NS * 2 / 16, QP = D + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const qs = reinterpret_cast<float*>(smem);
+    float* const mx = qs + 16 * QP;
+    float* const rinvs = mx + 256;
+    float* const ebuf = rinvs + 16;
+    float* const a1s = ebuf + 2 * FZ_EBUF;                                    // [FZ_MAX_L] the block's a1 per key
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, gq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = a.q_len, W = a.window, ncol = L - W;
+    const int n_blk = (L + 255) / 256, n_pad = (ncol + 1) & ~1;
+    const int tpw = ((L + 15) / 16 + FZ_WAVES - 1) / FZ_WAVES;             // key tiles per wave (<= FZ_TPW)
+    const FastMap fm = fast_map(a, blockIdx.x, n_blk, true);
+    const char* const ktb = reinterpret_cast<const char*>(a.kt) + ((int64_t)(fm.b * a.n_kv_heads + fm.g) * L) * (D * 2) + gq * (NS * 2);
+    const raw* const qb = reinterpret_cast<const raw*>(a.q) + (int64_t)fm.b * a.q_stride_b + (int64_t)fm.h * a.q_stride_h;
+    float* const part = a.part + ((int64_t)fm.hb * (n_blk + 1) + fm.blk) * n_pad;
+    float* const left = a.part + ((int64_t)fm.hb * (n_blk + 1) + n_blk) * n_pad;
+    const float sqrt_d = a.sqrt_d;
+    u32x32 Slo, Shi;                                                         // the sub-block's logits: tile i at dwords 2 i, 2 i + 1
+    for (int key = tid; key < FZ_MAX_L; key += FZ_THREADS) a1s[key] = 0.0f;   // (each key is only ever touched by the lane that owns it)
+    auto s_put = [&](int i, uint32_t w01, uint32_t w23) {
+        if (i < 16) { Slo[2 * i] = w01; Slo[2 * i + 1] = w23; } else { Shi[2 * i - 32] = w01; Shi[2 * i - 31] = w23; }
+    };
+    auto s_get = [&](int i, uint32_t& w01, uint32_t& w23) {
+        if (i < 16) { w01 = Slo[2 * i]; w23 = Slo[2 * i + 1]; } else { w01 = Shi[2 * i - 32]; w23 = Shi[2 * i - 31]; }
+    };
+    for (int sb = 0; sb < 16; ++sb) {
+        const int rb = fm.blk * 256 + sb * 16;
+        if (rb >= L) break;
+        const bool complete = rb + 16 <= L;
+        {   // Q rows -> fp32 MFMA operand: row offset rho sits in MFMA row slot 4 (rho & 3) + (rho >> 2)
+            constexpr int EPT = D / 64;
+            const int rho = tid >> 6, slot = 4 * (rho & 3) + (rho >> 2);
+            const int row = rb + rho < L ? rb + rho : L - 1;
+            const raw* qr = qb + (int64_t)row * a.q_stride_l + (tid & 63) * EPT;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int d = (tid & 63) * EPT + e;
+                qs[slot * QP + (d & 3) * NS + (d >> 2)] = Dt<DT>::ld(qr[e]);
+            }
+        }
+        __syncthreads();
+        // ---- A: logits -------------------------------------------------------------------------------------------
+        float rmax[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        // K operand: chunk c (16 bytes = 8 steps) of tile i is chunk number i * KV4 + c of the wave's stream; two chunks in flight
+        auto kchunk = [&](int q) {
+            const int i = q / KV4 < tpw ? q / KV4 : tpw - 1;
+            const int key = 16 * (16 * i + wave) + n;
+            return reinterpret_cast<const uint4*>(ktb + (int64_t)(key < L ? key : L - 1) * (D * 2))[q % KV4];
+        };
+        uint4 kreg[2] = {kchunk(0), kchunk(1)};
+        const float* const qrow = qs + n * QP + gq * NS;
+        for (int i = 0; i < tpw; ++i) {
+            f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < KV4; ++c) {
+                const uint4 kv = kreg[c & 1];
+                kreg[c & 1] = kchunk(i * KV4 + c + 2);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 qv = *reinterpret_cast<const f32x4*>(qrow + 8 * c + 4 * h);
+                    const uint32_t w0 = h ? kv.z : kv.x, w1 = h ? kv.w : kv.y;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[0], wide_lo<DT>(w0), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[1], wide_hi<DT>(w0), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[2], wide_lo<DT>(w1), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[3], wide_hi<DT>(w1), acc, 0, 0, 0);
+                }
+            }
+            const int t0 = 16 * (16 * i + wave), key = t0 + n;
+            const bool tail = t0 + 16 > L - W && rb + 16 > L - W;               // (uniform) the tile touches the masked window block
+            float x[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = rb + 4 * v + gq;
+                float y = rnd<DT>(acc[v]);
+                y = rnd<DT>(h2o_scale<D>(y, sqrt_d));
+                if (tail) {
+                    if (r >= L - W && key >= L - W && (key - (L - W)) > (r - (L - W))) y = rnd<DT>(y + Dt<DT>::finfo_min());
+                }
+                x[v] = y;
+                rmax[v] = (r < L && key < L && y > rmax[v]) ? y : rmax[v];
+            }
+            s_put(i, (uint32_t)Dt<DT>::st(x[0]) | ((uint32_t)Dt<DT>::st(x[1]) << 16), (uint32_t)Dt<DT>::st(x[2]) | ((uint32_t)Dt<DT>::st(x[3]) << 16));
+        }
+        // ---- B: row maxima across the 16 key lanes, then across the waves --------------------------------------------
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            float m = rmax[v], o;
+            o = xor_lane<1>(m); m = o > m ? o : m;
+            o = xor_lane<2>(m); m = o > m ? o : m;
+            o = xor_lane<4>(m); m = o > m ? o : m;
+            o = xor_lane<8>(m); m = o > m ? o : m;
+            if (n == 0) mx[(4 * v + gq) * 16 + wave] = m;
+        }
+        __syncthreads();
+        float m[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const f32x4* mp = reinterpret_cast<const f32x4*>(mx + (4 * v + gq) * 16);
+            float t = -__builtin_inff();
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 u = mp[q4];
+                t = u[0] > t ? u[0] : t; t = u[1] > t ? u[1] : t; t = u[2] > t ? u[2] : t; t = u[3] > t ? u[3] : t;
+            }
+            m[v] = t;
+        }
+        // ---- C: denominators in torch's order ---------------------------------------------------------------------------
+        float cacc = 0.0f;                                                   // waves 0-3: chain n of row 4 wave + gq
+        for (int rd = 0; 2 * rd < tpw; ++rd) {
+            float* const eb = ebuf + (rd & 1) * FZ_EBUF;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = 2 * rd + u;
+                if (i < tpw) {
+                    uint32_t w01, w23;
+                    s_get(i, w01, w23);
+                    const bool kvalid = 16 * (16 * i + wave) + n < L;
+                    const f32x2 e01 = exp_u20x2(f32x2{wide_lo<DT>(w01), wide_hi<DT>(w01)} - f32x2{m[0], m[1]});
+                    const f32x2 e23 = exp_u20x2(f32x2{wide_lo<DT>(w23), wide_hi<DT>(w23)} - f32x2{m[2], m[3]});
+                    float* const dst = eb + (u * 16 + wave) * 256 + lane;
+                    dst[0] = kvalid ? e01.x : 0.0f; dst[64] = kvalid ? e01.y : 0.0f;
+                    dst[128] = kvalid ? e23.x : 0.0f; dst[192] = kvalid ? e23.y : 0.0f;
+                }
+            }
+            __syncthreads();      // this round's exponentials are in the ring; the chain waves finished the previous round's half
+                                  // before they arrived here, so the workers may refill that half while this one is being added
+            if (wave < 4) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (2 * rd + u < tpw) {
+                        const float* src = eb + u * 16 * 256 + wave * 64 + lane;
+                        float t[16];
+#pragma unroll
+                        for (int w2 = 0; w2 < 16; ++w2) t[w2] = src[w2 * 256];
+#pragma unroll
+                        for (int w2 = 0; w2 < 16; ++w2) cacc = cacc + t[w2];
+                    }
+                }
+            }
+        }
+        if (wave < 4) {
+            float s2 = cacc;
+            s2 = s2 + xor_lane<8>(s2);
+            s2 = s2 + xor_lane<4>(s2);
+            s2 = s2 + xor_lane<2>(s2);
+            s2 = s2 + xor_lane<1>(s2);
+            if (n == 0) rinvs[4 * wave + gq] = 1.0f / s2;
+        }
+        __syncthreads();
+        float ri[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) ri[v] = rinvs[4 * v + gq];
+        // ---- D: probabilities, summed over the 16 rows in row order by the matrix core ------------------------------------------
+        for (int i = 0; i < tpw; ++i) {
+            uint32_t w01, w23;
+            s_get(i, w01, w23);
+            const int key = 16 * (16 * i + wave) + n;
+            const f32x2 p01 = exp_u20x2(f32x2{wide_lo<DT>(w01), wide_hi<DT>(w01)} - f32x2{m[0], m[1]}) * f32x2{ri[0], ri[1]};
+            const f32x2 p23 = exp_u20x2(f32x2{wide_lo<DT>(w23), wide_hi<DT>(w23)} - f32x2{m[2], m[3]}) * f32x2{ri[2], ri[3]};
+            float pv[4] = {rnd<DT>(p01.x), rnd<DT>(p01.y), rnd<DT>(p23.x), rnd<DT>(p23.y)};
+            f32x4 cs = {0, 0, 0, 0};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float pp = (key < L && rb + 4 * v + gq < L) ? pv[v] : 0.0f;
+                cs = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, pp, cs, 0, 0, 0);
+            }
+            const float a0 = cs[0];                                          // the 16-row sum of column `key` (every lane group holds a copy)
+            if (complete) {
+                if (gq == 0) a1s[key] = a1s[key] + a0;
+            } else if (gq == 0 && key < ncol) {
+                left[key] = a0;                                              // rows beyond the last full 16-row chunk stay in a0
+            }
+        }
+    }
+    __syncthreads();
+    for (int key = tid; key < ncol; key += FZ_THREADS) part[key] = a1s[key];
+    if (fm.blk == n_blk - 1 && (L & 15) == 0) {
+        for (int key = tid; key < ncol; key += FZ_THREADS) left[key] = 0.0f;
+    }
+}
+
 // Query rows per chunk of the exact mode's logit matrix S (multiple of 256: the column sums combine 256-row blocks): as
 // many as fit in kH2OSBudget bytes, at least 512 — [Hq][rows][L] instead of [Hq][L][L] (4.1 GB at 32 heads x 8k, 65 GB at 32k).
 constexpr size_t kH2OSBudget = (size_t)1 << 30;
@@ -752,12 +986,24 @@ static int launch_h2o_t(const H2OArgs& a0, hipStream_t st) {
             return 0;
         }
     }
+    bool wide = false;
+    if constexpr (DT != KVC_FP32) wide = (L % 8) == 0 && (a.window % 2) == 0 && L >= 16;
+    if constexpr (DT != KVC_FP32) {
+        if (!a.legacy && a.part && a.kt && L >= 16 && L <= FZ_MAX_L) {
+            const size_t lds_f = (size_t)(16 * (D + 4) + 256 + 16 + 2 * FZ_EBUF + FZ_MAX_L) * 4;
+            static LdsCache c_f = {};
+            if (ensure_lds(reinterpret_cast<const void*>(&h2o_fused_kernel<DT, D>), lds_f, c_f) != 0) return KVC_ERR_HIP;
+            hipLaunchKernelGGL((h2o_kperm_kernel<DT, D>), dim3((unsigned)((L * (D / 8) + 255) / 256), (unsigned)(a.bsz * a.n_kv_heads)), dim3(256), 0, st, a);
+            hipLaunchKernelGGL((h2o_fused_kernel<DT, D>), dim3((unsigned)(heads * ((L + 255) / 256))), dim3(FZ_THREADS), lds_f, st, a);
+            if (wide) hipLaunchKernelGGL((h2o_colcomb_kernel<DT>), dim3((unsigned)((n / 2 + 255) / 256), (unsigned)heads), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((h2o_colcomb1_kernel<DT>), dim3((unsigned)((n + 255) / 256), (unsigned)heads), dim3(256), 0, st, a);
+            return 0;
+        }
+    }
     const size_t lds = (size_t)4 * 2 * 32 * (D * ES + (DT == KVC_BF16 ? 4 : 0));   // 4 waves x 2 tile buffers (ROWP pitch)
     static LdsCache lds_cache = {};
     if (ensure_lds(reinterpret_cast<const void*>(&h2o_logits_kernel<DT, D>), lds, lds_cache) != 0) return KVC_ERR_HIP;
     const bool chunked = a.s_rows < L;
-    bool wide = false;
-    if constexpr (DT != KVC_FP32) wide = (L % 8) == 0 && (a.window % 2) == 0 && L >= 16;
     const bool parts = a.part != nullptr && (chunked || (wide && L >= 512));    // 256-row blocks combined afterwards
     if (chunked && !a.part) return KVC_ERR_WORKSPACE;
     for (int row0 = 0; row0 < L; row0 += a.s_rows) {

@@ -165,11 +165,31 @@ def test_h2o_row_chunks_equal_one_piece(kvc, oracle, gpu_device, dtype, L, W, D)
     via debug_stage_mask bit7) and combines the column sums of 256-row blocks in torch's cascade order: scores identical
     to the one-piece computation and to the oracle — pair form (L % 8 == 0), one-column form (odd L) and fp32."""
     q, k, v = G.synth.make_qkv(8, 2, L, D, dtype, 4000 + L, device=gpu_device)
-    one = kvc.scores(kvc.H2O, q, k, W, 7, None)
-    chunks = kvc.scores(kvc.H2O, q, k, W, 7, None, debug_mask=128)
+    one = kvc.scores(kvc.H2O, q, k, W, 7, None, debug_mask=2048)           # (bit 11: the materialising kernels; see the next test)
+    chunks = kvc.scores(kvc.H2O, q, k, W, 7, None, debug_mask=128 | 2048)
     assert torch.equal(G.bits(one), G.bits(chunks))
     sc_o = oracle.scores(q.cpu(), k.cpu(), W, 7, "avgpool", full_rows=True, dot_mode=oracle.DOT_CHAIN, sum_mode=oracle.SUM_TORCH16)
     assert torch.equal(G.bits(chunks[0]), G.bits(sc_o))
+
+
+@pytest.mark.parametrize("dtype,hq,hkv,L,W,D", [
+    (torch.bfloat16, 8, 2, 40, 8, 128), (torch.bfloat16, 8, 8, 257, 8, 128), (torch.float16, 4, 2, 300, 32, 64),
+    (torch.bfloat16, 4, 1, 512, 8, 128), (torch.float16, 8, 2, 1000, 8, 128), (torch.bfloat16, 8, 2, 1304, 16, 64),
+    (torch.bfloat16, 2, 1, 2049, 8, 128), (torch.bfloat16, 2, 2, 4112, 64, 128), (torch.float16, 1, 1, 8192, 8, 128),
+    (torch.bfloat16, 16, 8, 8000, 8, 128)])
+def test_h2o_fused_equals_materialising_form(kvc, oracle, gpu_device, dtype, hq, hkv, L, W, D):
+    """The exact H2O mode of 16-bit dtypes up to 8 192 keys runs as ONE kernel that keeps 16 query rows of the logit matrix in
+    registers (v_mfma_f32_16x16x4_f32 dot products, torch-order denominators through an LDS ring, the 16-row column sums
+    on the matrix core); debug_stage_mask bit11 selects round 2's kernels that write the logits to the workspace.  Same
+    bits from both, over ragged L (L % 16, L % 256 != 0), the window mask sizes, both head dims, GQA and the 8 192 limit;
+    the small ones also against the oracle."""
+    q, k, v = G.synth.make_qkv(hq, hkv, L, D, dtype, 5100 + L, device=gpu_device)
+    fused = kvc.scores(kvc.H2O, q, k, W, 7, None)
+    legacy = kvc.scores(kvc.H2O, q, k, W, 7, None, debug_mask=2048)
+    assert torch.equal(G.bits(fused), G.bits(legacy))
+    if L <= 1304:
+        sc_o = oracle.scores(q.cpu(), k.cpu(), W, 7, "avgpool", full_rows=True, dot_mode=oracle.DOT_CHAIN, sum_mode=oracle.SUM_TORCH16)
+        assert torch.equal(G.bits(fused[0]), G.bits(sc_o))
 
 
 @pytest.mark.parametrize("name", ["h2o_bf16_W8_L257", "h2o_fp16_W32_L300", "h2o_bf16_W32_L300", "C3_h2o_8k_2heads"])
