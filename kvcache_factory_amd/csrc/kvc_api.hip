@@ -104,7 +104,7 @@ Layout carve(const kvc_params* p, int n_items = 1) {
         if (l.h2o_rows > 512 && (p->debug_stage_mask & 128)) l.h2o_rows = 512;      // testing aid: several chunks at small L
         // logits: [h][L][W] for the window methods; H2O exact: the chunk [h][h2o_rows][L]; H2O fast: nothing
         // (H2O exact, fused form: the same region holds the permuted copy of K, [bsz * Hkv][L][D])
-        const size_t h2o_kt = (size_t)p->bsz * p->n_kv_heads * L * p->head_dim * es;
+        const size_t h2o_kt = (size_t)p->bsz * p->n_kv_heads * ((L + 15) / 16 * 16) * p->head_dim * es;
         const size_t h2o_s = heads * (size_t)l.h2o_rows * L * es;
         l.logits = off; off = align_up(off + (p->method == KVC_H2O ? (h2o_fast ? 0 : (h2o_s > h2o_kt ? h2o_s : h2o_kt)) : heads * L * R * es), 256);
         l.pmax = off;   off = align_up(off + (p->method == KVC_H2O ? 0 : heads * (size_t)l.n_tiles * W * 4), 256);

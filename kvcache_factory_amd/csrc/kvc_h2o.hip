@@ -750,22 +750,33 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x32 __attribute__((ext_vector_type(32)));
 constexpr int FZ_WAVES = 16, FZ_THREADS = 64 * FZ_WAVES, FZ_TPW = 32, FZ_MAX_L = 16 * FZ_WAVES * FZ_TPW;   // 8192 keys
 constexpr int FZ_EBUF = 32 * 4 * 64;                         // floats per ring half: 32 tile slots x 4 registers x 64 lanes
+constexpr int FZ_RING = 4;                                   // 1 KB chunks of K per wave in LDS (phase A)
+constexpr size_t fz_lds_bytes(int D) {
+    const size_t x = (size_t)2 * FZ_EBUF * 4, r = (size_t)FZ_WAVES * FZ_RING * 1024;
+    return (size_t)(16 * (D + 4) + 256 + 16 + FZ_MAX_L) * 4 + (x > r ? x : r);
+}
 
-// Kt[b][g][key][gq * (D/4) + s] = K[b][g][key][4 s + gq].  grid = (ceil(L * D / 8 / 256), bsz * n_kv_heads), block = 256.
+// The B operand of lane (key n, k-slot gq) over a tile's D / 4 steps is K[key][gq], K[key][4 + gq], ...: 2-byte elements 8 bytes
+// apart.  h2o_kperm_kernel lays K out as the waves will load it: Kt[b][g][tile][chunk c][lane = 16 gq + n] = the 16 bytes
+// {K[16 tile + n][4 s + gq] : s = 8 c .. 8 c + 7} — one global_load_dwordx4 of a wave reads 1 KB of contiguous memory
+// (a first version kept the permutation inside each 256-byte row: every load touched all 32 cache lines of the tile and the
+// kernel was bound by L1 refills).  Keys beyond L are zeros.  grid = (ceil(tiles * D/8 * 16 / 256), bsz * n_kv_heads), block = 256.
 template <int DT, int D>
 __global__ __launch_bounds__(256) void h2o_kperm_kernel(const H2OArgs a) {
     typedef typename Dt<DT>::raw raw;
-    constexpr int NS = D / 4, CPR = D / 8;
-    const int L = a.q_len, bg = blockIdx.y, b = bg / a.n_kv_heads, g = bg % a.n_kv_heads;
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= L * CPR) return;
-    const int key = c / CPR, p0 = (c % CPR) * 8, gq = p0 / NS, s0 = p0 % NS;
-    const raw* kr = reinterpret_cast<const raw*>(a.k) + (int64_t)b * a.k_stride_b + (int64_t)g * a.k_stride_h + (int64_t)key * a.k_stride_l;
-    uint32_t w[4];
+    constexpr int KV4 = D / 32;
+    const int L = a.q_len, n_tiles = (L + 15) / 16, bg = blockIdx.y, b = bg / a.n_kv_heads, g = bg % a.n_kv_heads;
+    const int o = blockIdx.x * 256 + threadIdx.x;                             // output uint4 index within the head
+    if (o >= n_tiles * KV4 * 64) return;
+    const int lane = o & 63, c = (o >> 6) % KV4, tile = (o >> 6) / KV4, n = lane & 15, gq = lane >> 4, key = 16 * tile + n;
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (key < L) {
+        const raw* kr = reinterpret_cast<const raw*>(a.k) + (int64_t)b * a.k_stride_b + (int64_t)g * a.k_stride_h + (int64_t)key * a.k_stride_l;
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-        w[e] = (uint32_t)kr[4 * (s0 + 2 * e) + gq] | ((uint32_t)kr[4 * (s0 + 2 * e + 1) + gq] << 16);
-    reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.kt) + ((int64_t)bg * L + key) * (D * 2))[c % CPR] = make_uint4(w[0], w[1], w[2], w[3]);
+        for (int e = 0; e < 4; ++e)
+            w[e] = (uint32_t)kr[4 * (8 * c + 2 * e) + gq] | ((uint32_t)kr[4 * (8 * c + 2 * e + 1) + gq] << 16);
+    }
+    reinterpret_cast<uint4*>(a.kt)[(int64_t)bg * n_tiles * KV4 * 64 + o] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 template <int DT> __device__ __forceinline__ float wide_lo(uint32_t w) {
@@ -774,36 +785,106 @@ template <int DT> __device__ __forceinline__ float wide_lo(uint32_t w) {
 template <int DT> __device__ __forceinline__ float wide_hi(uint32_t w) {
     if constexpr (DT == KVC_BF16) return u2f(w & 0xffff0000u); else return Dt<DT>::ld((uint16_t)(w >> 16));
 }
+// two values rounded to the storage dtype, packed (low half = first)
+template <int DT> __device__ __forceinline__ uint32_t pack2(f32x2 v) {
+    if constexpr (DT == KVC_BF16) {
+        asm volatile("" : "+v"(v));
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));                   // v_cvt_pk_bf16_f32
+    } else {
+        return (uint32_t)Dt<DT>::st(v.x) | ((uint32_t)Dt<DT>::st(v.y) << 16);
+    }
+}
+// exp_u20x2 for arguments <= 0 (logit minus its row maximum), bit-identical to it there with 10 instructions fewer: no
+// upper clamp; the clamped input ln(FLT_MIN) yields fx = -126 and so 2^n = bits 0 = +0.0 — what the `below` select of
+// exp_u20x2 returns — and (int)(fx - 1) + 127 = (int)fx + 126 because fx is integral.  (An argument > 0 or NaN can
+// only come from a query row beyond L, whose results are discarded.)
+__device__ __forceinline__ f32x2 exp_u20x2_nonpos(f32x2 x) {
+    const float ln_flt_min = u2f(0xc2aeac50u);
+    const f32x2 log2ef = u2f(0x3fb8aa3bu), nln2f = -u2f(0x3f317218u);
+    const f32x2 c1 = 0.999999701f, c2 = 0.499991506f, c3 = 0.166676521f, c4 = 0.0418978221f, c5 = 0.00828929059f;
+    f32x2 s_;
+    s_.x = (x.x > ln_flt_min) ? x.x : ln_flt_min;
+    s_.y = (x.y > ln_flt_min) ? x.y : ln_flt_min;
+    f32x2 fx = __builtin_elementwise_fma(s_, log2ef, (f32x2)0.5f);
+    fx.x = __builtin_floorf(fx.x); fx.y = __builtin_floorf(fx.y);
+    const f32x2 r = __builtin_elementwise_fma(fx, nln2f, s_);
+    f32x2 p = __builtin_elementwise_fma(r, c5, c4);
+    p = __builtin_elementwise_fma(r, p, c3);
+    p = __builtin_elementwise_fma(r, p, c2);
+    p = __builtin_elementwise_fma(r, p, c1);
+    p = __builtin_elementwise_fma(r, p, (f32x2)1.0f);
+    f32x2 two_n;
+    two_n.x = u2f((uint32_t)((int)fx.x + 126) << 23);
+    two_n.y = u2f((uint32_t)((int)fx.y + 126) << 23);
+    p = p * two_n;
+    p = p * (f32x2)2.0f;
+    return p;
+}
+// One group of four MFMA steps of the fused kernel: A = four fp32 values of the lane's Q row slot, B = four bf16 elements of
+// the lane's 16-byte K chunk widened by the load (kvc_ldsasm.h).  5 LDS reads; retired by wait_step.
+template <int QOFF, int KOFF> __device__ __forceinline__ void fz_ld(f32x4& A, uint32_t (&B)[4], uint32_t q_a, uint32_t k_a) {
+    asm volatile("ds_read_b128 %0, %5 offset:%7\n\t"
+                 "ds_read_u16_d16_hi %1, %6 offset:%8\n\t"
+                 "ds_read_u16_d16_hi %2, %6 offset:%9\n\t"
+                 "ds_read_u16_d16_hi %3, %6 offset:%10\n\t"
+                 "ds_read_u16_d16_hi %4, %6 offset:%11"
+                 : KVC_LD_OUT(A), KVC_LD_OUT(B[0]), KVC_LD_OUT(B[1]), KVC_LD_OUT(B[2]), KVC_LD_OUT(B[3])
+                 : "v"(q_a), "v"(k_a), "n"(QOFF), "n"(KOFF), "n"(KOFF + 2), "n"(KOFF + 4), "n"(KOFF + 6)
+                 : "memory");
+}
 
-// grid = bsz * n_q_heads * ceil(L / 256), block = 1024.  LDS: Q operand [16][D + 4] f32, maxima [16][16], rinv [16], ring 2 x FZ_EBUF, a1 [8192].
+// grid = bsz * n_q_heads * ceil(L / 256), block = 1024.
+// LDS: Q operand [16][D + 4] f32, maxima [16][16], rinv [16], a1 [8192], then the K rings (phase A) / the exponentials' ring (phase C).
 template <int DT, int D>
 __global__ __launch_bounds__(FZ_THREADS) void h2o_fused_kernel(const H2OArgs a) {
     typedef typename Dt<DT>::raw raw;
-    constexpr int NS = D / 4, KV4 = NS * 2 / 16, QP = D + 4;
+    constexpr int NS = D / 4, KV4 = NS * 2 / 16, QP = D + 4, NG = NS / 4;       // NG groups of four MFMA steps per tile
+    static_assert(FZ_RING % KV4 == 0 && FZ_RING - 1 <= 2 * KV4, "ring slots follow the tile's chunks");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const qs = reinterpret_cast<float*>(smem);
     float* const mx = qs + 16 * QP;
     float* const rinvs = mx + 256;
-    float* const ebuf = rinvs + 16;
-    float* const a1s = ebuf + 2 * FZ_EBUF;                                    // [FZ_MAX_L] the block's a1 per key
+    float* const a1s = rinvs + 16;                                           // [FZ_MAX_L] the block's a1 per key
+    float* const ebuf = a1s + FZ_MAX_L;                                      // phase C: the exponentials' ring; phase A: the K rings
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, gq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = a.q_len, W = a.window, ncol = L - W;
     const int n_blk = (L + 255) / 256, n_pad = (ncol + 1) & ~1;
-    const int tpw = ((L + 15) / 16 + FZ_WAVES - 1) / FZ_WAVES;             // key tiles per wave (<= FZ_TPW)
+    const int n_tiles = (L + 15) / 16, tpw = (n_tiles + FZ_WAVES - 1) / FZ_WAVES;   // key tiles per wave (<= FZ_TPW)
     const FastMap fm = fast_map(a, blockIdx.x, n_blk, true);
-    const char* const ktb = reinterpret_cast<const char*>(a.kt) + ((int64_t)(fm.b * a.n_kv_heads + fm.g) * L) * (D * 2) + gq * (NS * 2);
+    uint64_t ktb;                                                            // (scalar) the head's permuted K
+    {
+        const uint64_t pk = (uint64_t)(uintptr_t)a.kt + (uint64_t)(fm.b * a.n_kv_heads + fm.g) * (uint64_t)n_tiles * (KV4 * 1024);
+        ktb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pk >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pk);
+    }
+    uint32_t lane16 = lane * 16;
     const raw* const qb = reinterpret_cast<const raw*>(a.q) + (int64_t)fm.b * a.q_stride_b + (int64_t)fm.h * a.q_stride_h;
     float* const part = a.part + ((int64_t)fm.hb * (n_blk + 1) + fm.blk) * n_pad;
     float* const left = a.part + ((int64_t)fm.hb * (n_blk + 1) + n_blk) * n_pad;
     const float sqrt_d = a.sqrt_d;
+    const char* const ring = reinterpret_cast<const char*>(ebuf) + wave * (FZ_RING * 1024);
+    const uint32_t ring_base = __builtin_amdgcn_readfirstlane(lds_addr(ring));
     u32x32 Slo, Shi;                                                         // the sub-block's logits: tile i at dwords 2 i, 2 i + 1
     for (int key = tid; key < FZ_MAX_L; key += FZ_THREADS) a1s[key] = 0.0f;   // (each key is only ever touched by the lane that owns it)
+#ifdef KVC_STAMPS
+    uint64_t fz_t[6] = {0, 0, 0, 0, 0, 0}, fz_last = __builtin_amdgcn_s_memtime();
+#define KVC_FZ_STAMP(i_) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); fz_t[i_] += t_ - fz_last; fz_last = t_; }
+#else
+#define KVC_FZ_STAMP(i_)
+#endif
     auto s_put = [&](int i, uint32_t w01, uint32_t w23) {
         if (i < 16) { Slo[2 * i] = w01; Slo[2 * i + 1] = w23; } else { Shi[2 * i - 32] = w01; Shi[2 * i - 31] = w23; }
     };
     auto s_get = [&](int i, uint32_t& w01, uint32_t& w23) {
         if (i < 16) { w01 = Slo[2 * i]; w23 = Slo[2 * i + 1]; } else { w01 = Shi[2 * i - 32]; w23 = Shi[2 * i - 31]; }
+    };
+    // K operand: chunk c (16 bytes per lane = 8 steps) of tile i is chunk q = i * KV4 + c of the wave's stream and lives in ring
+    // slot q % FZ_RING.  The chunks travel global -> LDS without passing through registers (global_load_lds_dwordx4: lane l's
+    // 16 bytes land at M0 + 16 l), FZ_RING - 2 chunks ahead of the MFMAs that use them.  vmcnt: these loads are the wave's only
+    // vector-memory operations in phase A and complete in order.
+    auto tile_src = [&](int i) {                                             // (scalar) tile 16 i + wave of the stream, clamped
+        const int t = 16 * i + wave;
+        return ktb + (uint64_t)(t < n_tiles ? t : n_tiles - 1) * (KV4 * 1024);
     };
     for (int sb = 0; sb < 16; ++sb) {
         const int rb = fm.blk * 256 + sb * 16;
@@ -821,52 +902,116 @@ __global__ __launch_bounds__(FZ_THREADS) void h2o_fused_kernel(const H2OArgs a) 
             }
         }
         __syncthreads();
+        KVC_FZ_STAMP(0)
         // ---- A: logits -------------------------------------------------------------------------------------------
         float rmax[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-        // K operand: chunk c (16 bytes = 8 steps) of tile i is chunk number i * KV4 + c of the wave's stream; two chunks in flight
-        auto kchunk = [&](int q) {
-            const int i = q / KV4 < tpw ? q / KV4 : tpw - 1;
-            const int key = 16 * (16 * i + wave) + n;
-            return reinterpret_cast<const uint4*>(ktb + (int64_t)(key < L ? key : L - 1) * (D * 2))[q % KV4];
+        uint64_t src[3] = {tile_src(0), tile_src(1), tile_src(2)};           // the tiles whose chunks are being fetched (SGPR pairs)
+        auto kdma = [ring_base, lane16](uint64_t sp, auto coff_, uint32_t slot) {
+            constexpr int coff = decltype(coff_)::value;
+            const uint32_t dst = ring_base + slot * 1024u;
+            // (an instruction offset would move the LDS destination as well as the source: the chunk offset goes into the scalar base)
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(lane16), "s"(sp + (uint64_t)(coff * 1024)) : "memory", "m0");
         };
-        uint4 kreg[2] = {kchunk(0), kchunk(1)};
-        const float* const qrow = qs + n * QP + gq * NS;
+        static_for<0, FZ_RING - 1>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+            kdma(src[q / KV4], std::integral_constant<int, q % KV4>{}, (uint32_t)q);
+        });
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FZ_RING - 2) : "memory");  // chunk 0 has landed
+        const uint32_t q_a = lds_addr(qs + n * QP + gq * NS), k_a0 = lds_addr(ring) + lane * 16;
         for (int i = 0; i < tpw; ++i) {
+            const uint32_t ring_i = (uint32_t)((i * KV4) % FZ_RING);          // slot of this tile's chunk 0 (uniform)
+            const uint32_t k_a = k_a0 + ring_i * 1024u;
             f32x4 acc = {0, 0, 0, 0};
+            if constexpr (DT == KVC_BF16) {
+                f32x4 A0, A1;
+                uint32_t B0[4], B1[4];
+                fz_ld<0, 0>(A0, B0, q_a, k_a);
+                static_for<0, NG>([&](auto g_) {
+                    constexpr int g = decltype(g_)::value, c = g / 2;
+                    f32x4& Ac = (g & 1) ? A1 : A0;
+                    uint32_t (&Bc)[4] = (g & 1) ? B1 : B0;
+                    if constexpr ((g & 1) == 0) {                           // first group of chunk c: fetch chunk q + RING - 1, chunk q + 1 must be there
+                        constexpr int ahead = c + FZ_RING - 1;
+                        kdma(src[ahead / KV4], std::integral_constant<int, ahead % KV4>{}, (ring_i + (uint32_t)ahead) % FZ_RING);
+                        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FZ_RING - 2) : "memory");
+                    }
+                    if constexpr (g + 1 < NG) {
+                        fz_ld<16 * (g + 1), ((g + 1) / 2) * 1024 + ((g + 1) & 1) * 8>((g & 1) ? A0 : A1, (g & 1) ? B0 : B1, q_a, k_a);
+                        wait_step<5>(Ac, Bc);
+                    } else {
+                        wait_step<0>(Ac, Bc);
+                    }
 #pragma unroll
-            for (int c = 0; c < KV4; ++c) {
-                const uint4 kv = kreg[c & 1];
-                kreg[c & 1] = kchunk(i * KV4 + c + 2);
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ac[e], u2f(Bc[e]), acc, 0, 0, 0);
+                });
+            } else {
+                const float* const qrow = qs + n * QP + gq * NS;
+                static_for<0, KV4>([&](auto c_) {
+                    constexpr int c = decltype(c_)::value, ahead = c + FZ_RING - 1;
+                    kdma(src[ahead / KV4], std::integral_constant<int, ahead % KV4>{}, (ring_i + (uint32_t)ahead) % FZ_RING);
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FZ_RING - 1) : "memory");   // chunk q has landed
+                    const uint4 kv = *reinterpret_cast<const uint4*>(ring + ((ring_i + c) % FZ_RING) * 1024 + lane * 16);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f32x4 qv = *reinterpret_cast<const f32x4*>(qrow + 8 * c + 4 * h);
-                    const uint32_t w0 = h ? kv.z : kv.x, w1 = h ? kv.w : kv.y;
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[0], wide_lo<DT>(w0), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[1], wide_hi<DT>(w0), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[2], wide_lo<DT>(w1), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[3], wide_hi<DT>(w1), acc, 0, 0, 0);
-                }
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 qv = *reinterpret_cast<const f32x4*>(qrow + 8 * c + 4 * h);
+                        const uint32_t w0 = h ? kv.z : kv.x, w1 = h ? kv.w : kv.y;
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[0], wide_lo<DT>(w0), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[1], wide_hi<DT>(w0), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[2], wide_lo<DT>(w1), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[3], wide_hi<DT>(w1), acc, 0, 0, 0);
+                    }
+                });
             }
+            src[0] = src[1]; src[1] = src[2]; src[2] = tile_src(i + 3);
             const int t0 = 16 * (16 * i + wave), key = t0 + n;
             const bool tail = t0 + 16 > L - W && rb + 16 > L - W;               // (uniform) the tile touches the masked window block
-            float x[4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int r = rb + 4 * v + gq;
-                float y = rnd<DT>(acc[v]);
-                y = rnd<DT>(h2o_scale<D>(y, sqrt_d));
-                if (tail) {
-                    if (r >= L - W && key >= L - W && (key - (L - W)) > (r - (L - W))) y = rnd<DT>(y + Dt<DT>::finfo_min());
+            uint32_t w01, w23;
+            if (!tail && t0 + 16 <= L && rb + 16 <= L) {
+                // every row and key of the tile is valid and unmasked: packed arithmetic, one guard for the four values
+                const f32x2 y01 = round2<DT>(f32x2{acc[0], acc[1]}), y23 = round2<DT>(f32x2{acc[2], acc[3]});
+                f32x2 z01, z23;
+                if constexpr (D == 64) {
+                    z01 = y01 * (f32x2)0.125f; z23 = y23 * (f32x2)0.125f;
+                } else {
+                    const f32x2 rc = u2f(0x3db504f3u), cc = sqrt_d;             // the 2-FMA division of h2o_scale, on pairs
+                    const f32x2 q01 = y01 * rc, q23 = y23 * rc;
+                    z01 = __builtin_elementwise_fma(__builtin_elementwise_fma(-q01, cc, y01), rc, q01);
+                    z23 = __builtin_elementwise_fma(__builtin_elementwise_fma(-q23, cc, y23), rc, q23);
+                    const float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(y01.x), __builtin_fabsf(y01.y)), __builtin_fminf(__builtin_fabsf(y23.x), __builtin_fabsf(y23.y)));
+                    const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(y01.x), __builtin_fabsf(y01.y)), __builtin_fmaxf(__builtin_fabsf(y23.x), __builtin_fabsf(y23.y)));
+                    if (__builtin_expect(!(lo >= u2f(0x0d800000u) && hi < __builtin_inff()), 0)) {   // outside the proven range: IEEE division
+                        z01 = f32x2{h2o_scale<D>(y01.x, sqrt_d), h2o_scale<D>(y01.y, sqrt_d)};
+                        z23 = f32x2{h2o_scale<D>(y23.x, sqrt_d), h2o_scale<D>(y23.y, sqrt_d)};
+                    }
                 }
-                x[v] = y;
-                rmax[v] = (r < L && key < L && y > rmax[v]) ? y : rmax[v];
+                // (rounding is monotone: the maximum of the rounded logits is the rounded maximum — rmax is rounded once, below)
+                rmax[0] = __builtin_fmaxf(rmax[0], z01.x); rmax[1] = __builtin_fmaxf(rmax[1], z01.y);
+                rmax[2] = __builtin_fmaxf(rmax[2], z23.x); rmax[3] = __builtin_fmaxf(rmax[3], z23.y);
+                w01 = pack2<DT>(z01); w23 = pack2<DT>(z23);
+            } else {
+                float x[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int r = rb + 4 * v + gq;
+                    float y = rnd<DT>(acc[v]);
+                    y = rnd<DT>(h2o_scale<D>(y, sqrt_d));
+                    if (tail) {
+                        if (r >= L - W && key >= L - W && (key - (L - W)) > (r - (L - W))) y = rnd<DT>(y + Dt<DT>::finfo_min());
+                    }
+                    x[v] = y;
+                    rmax[v] = (r < L && key < L && y > rmax[v]) ? y : rmax[v];
+                }
+                w01 = (uint32_t)Dt<DT>::st(x[0]) | ((uint32_t)Dt<DT>::st(x[1]) << 16);
+                w23 = (uint32_t)Dt<DT>::st(x[2]) | ((uint32_t)Dt<DT>::st(x[3]) << 16);
             }
-            s_put(i, (uint32_t)Dt<DT>::st(x[0]) | ((uint32_t)Dt<DT>::st(x[1]) << 16), (uint32_t)Dt<DT>::st(x[2]) | ((uint32_t)Dt<DT>::st(x[3]) << 16));
+            s_put(i, w01, w23);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the ring (aliased by the exponentials' ring) is quiet
+        KVC_FZ_STAMP(1)
         // ---- B: row maxima across the 16 key lanes, then across the waves --------------------------------------------
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            float m = rmax[v], o;
+            float m = rnd<DT>(rmax[v]), o;
             o = xor_lane<1>(m); m = o > m ? o : m;
             o = xor_lane<2>(m); m = o > m ? o : m;
             o = xor_lane<4>(m); m = o > m ? o : m;
@@ -874,18 +1019,23 @@ __global__ __launch_bounds__(FZ_THREADS) void h2o_fused_kernel(const H2OArgs a) 
             if (n == 0) mx[(4 * v + gq) * 16 + wave] = m;
         }
         __syncthreads();
-        float m[4];
+        f32x2 nm01, nm23;                                                   // minus the row maxima of rows gq, 4 + gq | 8 + gq, 12 + gq
+        {
+            float m[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const f32x4* mp = reinterpret_cast<const f32x4*>(mx + (4 * v + gq) * 16);
-            float t = -__builtin_inff();
+            for (int v = 0; v < 4; ++v) {
+                const f32x4* mp = reinterpret_cast<const f32x4*>(mx + (4 * v + gq) * 16);
+                float t = -__builtin_inff();
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const f32x4 u = mp[q4];
-                t = u[0] > t ? u[0] : t; t = u[1] > t ? u[1] : t; t = u[2] > t ? u[2] : t; t = u[3] > t ? u[3] : t;
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 u = mp[q4];
+                    t = u[0] > t ? u[0] : t; t = u[1] > t ? u[1] : t; t = u[2] > t ? u[2] : t; t = u[3] > t ? u[3] : t;
+                }
+                m[v] = t;
             }
-            m[v] = t;
+            nm01 = f32x2{-m[0], -m[1]}; nm23 = f32x2{-m[2], -m[3]};
         }
+        KVC_FZ_STAMP(2)
         // ---- C: denominators in torch's order ---------------------------------------------------------------------------
         float cacc = 0.0f;                                                   // waves 0-3: chain n of row 4 wave + gq
         for (int rd = 0; 2 * rd < tpw; ++rd) {
@@ -896,12 +1046,16 @@ __global__ __launch_bounds__(FZ_THREADS) void h2o_fused_kernel(const H2OArgs a) 
                 if (i < tpw) {
                     uint32_t w01, w23;
                     s_get(i, w01, w23);
-                    const bool kvalid = 16 * (16 * i + wave) + n < L;
-                    const f32x2 e01 = exp_u20x2(f32x2{wide_lo<DT>(w01), wide_hi<DT>(w01)} - f32x2{m[0], m[1]});
-                    const f32x2 e23 = exp_u20x2(f32x2{wide_lo<DT>(w23), wide_hi<DT>(w23)} - f32x2{m[2], m[3]});
+                    f32x2 e01 = exp_u20x2_nonpos(f32x2{wide_lo<DT>(w01), wide_hi<DT>(w01)} + nm01);
+                    f32x2 e23 = exp_u20x2_nonpos(f32x2{wide_lo<DT>(w23), wide_hi<DT>(w23)} + nm23);
+                    const int t0 = 16 * (16 * i + wave);
+                    if (t0 + 16 > L) {                                       // (uniform) keys beyond L add nothing
+                        const bool kvalid = t0 + n < L;
+                        e01.x = kvalid ? e01.x : 0.0f; e01.y = kvalid ? e01.y : 0.0f;
+                        e23.x = kvalid ? e23.x : 0.0f; e23.y = kvalid ? e23.y : 0.0f;
+                    }
                     float* const dst = eb + (u * 16 + wave) * 256 + lane;
-                    dst[0] = kvalid ? e01.x : 0.0f; dst[64] = kvalid ? e01.y : 0.0f;
-                    dst[128] = kvalid ? e23.x : 0.0f; dst[192] = kvalid ? e23.y : 0.0f;
+                    dst[0] = e01.x; dst[64] = e01.y; dst[128] = e23.x; dst[192] = e23.y;
                 }
             }
             __syncthreads();      // this round's exponentials are in the ring; the chain waves finished the previous round's half
@@ -910,10 +1064,10 @@ __global__ __launch_bounds__(FZ_THREADS) void h2o_fused_kernel(const H2OArgs a) 
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     if (2 * rd + u < tpw) {
-                        const float* src = eb + u * 16 * 256 + wave * 64 + lane;
+                        const float* srcp = eb + u * 16 * 256 + wave * 64 + lane;
                         float t[16];
 #pragma unroll
-                        for (int w2 = 0; w2 < 16; ++w2) t[w2] = src[w2 * 256];
+                        for (int w2 = 0; w2 < 16; ++w2) t[w2] = srcp[w2 * 256];
 #pragma unroll
                         for (int w2 = 0; w2 < 16; ++w2) cacc = cacc + t[w2];
                     }
@@ -929,23 +1083,25 @@ __global__ __launch_bounds__(FZ_THREADS) void h2o_fused_kernel(const H2OArgs a) 
             if (n == 0) rinvs[4 * wave + gq] = 1.0f / s2;
         }
         __syncthreads();
-        float ri[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) ri[v] = rinvs[4 * v + gq];
+        const f32x2 ri01 = {rinvs[gq], rinvs[4 + gq]}, ri23 = {rinvs[8 + gq], rinvs[12 + gq]};
+        KVC_FZ_STAMP(3)
         // ---- D: probabilities, summed over the 16 rows in row order by the matrix core ------------------------------------------
         for (int i = 0; i < tpw; ++i) {
             uint32_t w01, w23;
             s_get(i, w01, w23);
-            const int key = 16 * (16 * i + wave) + n;
-            const f32x2 p01 = exp_u20x2(f32x2{wide_lo<DT>(w01), wide_hi<DT>(w01)} - f32x2{m[0], m[1]}) * f32x2{ri[0], ri[1]};
-            const f32x2 p23 = exp_u20x2(f32x2{wide_lo<DT>(w23), wide_hi<DT>(w23)} - f32x2{m[2], m[3]}) * f32x2{ri[2], ri[3]};
-            float pv[4] = {rnd<DT>(p01.x), rnd<DT>(p01.y), rnd<DT>(p23.x), rnd<DT>(p23.y)};
-            f32x4 cs = {0, 0, 0, 0};
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float pp = (key < L && rb + 4 * v + gq < L) ? pv[v] : 0.0f;
-                cs = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, pp, cs, 0, 0, 0);
+            const int t0 = 16 * (16 * i + wave), key = t0 + n;
+            f32x2 p01 = round2<DT>(exp_u20x2_nonpos(f32x2{wide_lo<DT>(w01), wide_hi<DT>(w01)} + nm01) * ri01);
+            f32x2 p23 = round2<DT>(exp_u20x2_nonpos(f32x2{wide_lo<DT>(w23), wide_hi<DT>(w23)} + nm23) * ri23);
+            if (t0 + 16 > L || !complete) {                                  // (uniform) rows / keys beyond L add nothing
+                const bool kvalid = key < L;
+                p01.x = (kvalid && rb + gq < L) ? p01.x : 0.0f; p01.y = (kvalid && rb + 4 + gq < L) ? p01.y : 0.0f;
+                p23.x = (kvalid && rb + 8 + gq < L) ? p23.x : 0.0f; p23.y = (kvalid && rb + 12 + gq < L) ? p23.y : 0.0f;
             }
+            f32x4 cs = {0, 0, 0, 0};
+            cs = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, p01.x, cs, 0, 0, 0);
+            cs = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, p01.y, cs, 0, 0, 0);
+            cs = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, p23.x, cs, 0, 0, 0);
+            cs = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, p23.y, cs, 0, 0, 0);
             const float a0 = cs[0];                                          // the 16-row sum of column `key` (every lane group holds a copy)
             if (complete) {
                 if (gq == 0) a1s[key] = a1s[key] + a0;
@@ -953,7 +1109,14 @@ __global__ __launch_bounds__(FZ_THREADS) void h2o_fused_kernel(const H2OArgs a) 
                 left[key] = a0;                                              // rows beyond the last full 16-row chunk stay in a0
             }
         }
+        KVC_FZ_STAMP(4)
     }
+#ifdef KVC_STAMPS
+    if (lane == 0 && (wave == 0 || wave == 5)) {
+        uint64_t* o = reinterpret_cast<uint64_t*>(a.scores) + ((int64_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
+        for (int e = 0; e < 5; ++e) o[e] = fz_t[e];
+    }
+#endif
     __syncthreads();
     for (int key = tid; key < ncol; key += FZ_THREADS) part[key] = a1s[key];
     if (fm.blk == n_blk - 1 && (L & 15) == 0) {
@@ -990,13 +1153,15 @@ static int launch_h2o_t(const H2OArgs& a0, hipStream_t st) {
     if constexpr (DT != KVC_FP32) wide = (L % 8) == 0 && (a.window % 2) == 0 && L >= 16;
     if constexpr (DT != KVC_FP32) {
         if (!a.legacy && a.part && a.kt && L >= 16 && L <= FZ_MAX_L) {
-            const size_t lds_f = (size_t)(16 * (D + 4) + 256 + 16 + 2 * FZ_EBUF + FZ_MAX_L) * 4;
+            const size_t lds_f = fz_lds_bytes(D);
             static LdsCache c_f = {};
             if (ensure_lds(reinterpret_cast<const void*>(&h2o_fused_kernel<DT, D>), lds_f, c_f) != 0) return KVC_ERR_HIP;
-            hipLaunchKernelGGL((h2o_kperm_kernel<DT, D>), dim3((unsigned)((L * (D / 8) + 255) / 256), (unsigned)(a.bsz * a.n_kv_heads)), dim3(256), 0, st, a);
+            hipLaunchKernelGGL((h2o_kperm_kernel<DT, D>), dim3((unsigned)((((L + 15) / 16) * (D / 32) * 64 + 255) / 256), (unsigned)(a.bsz * a.n_kv_heads)), dim3(256), 0, st, a);
             hipLaunchKernelGGL((h2o_fused_kernel<DT, D>), dim3((unsigned)(heads * ((L + 255) / 256))), dim3(FZ_THREADS), lds_f, st, a);
+#ifndef KVC_STAMPS
             if (wide) hipLaunchKernelGGL((h2o_colcomb_kernel<DT>), dim3((unsigned)((n / 2 + 255) / 256), (unsigned)heads), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((h2o_colcomb1_kernel<DT>), dim3((unsigned)((n + 255) / 256), (unsigned)heads), dim3(256), 0, st, a);
+#endif
             return 0;
         }
     }

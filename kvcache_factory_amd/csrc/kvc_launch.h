@@ -44,7 +44,7 @@ struct H2OArgs {
     void* S;               // [bsz*Hq][s_rows][L] dtype logits of the query rows [row0, row0 + rows) (exact mode)
     int row0, rows, s_rows;    // the chunk of query rows in flight and the row capacity of S per head (launcher-set)
     int fast;              // 1: dot_mode mfma16 — two recomputing passes on the bf16/fp16 MFMA, no S at all
-    void* kt;              // exact mode, fused form: [bsz*Hkv][L][D] dtype, K with each row's dims dealt to the four MFMA k-slots
+    void* kt;              // exact mode, fused form: [bsz*Hkv][ceil(L/16)][D/32][64 lanes][16 B], K as the MFMA B operand is loaded
     int legacy;            // 1: round 2's materialising exact kernels (debug_stage_mask bit 11)
     float* rowmax;         // [bsz*Hq][L]   (fast mode: -max * log2(e))
     float* rinv;           // [bsz*Hq][L]
