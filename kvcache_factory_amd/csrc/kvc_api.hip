@@ -106,7 +106,8 @@ Layout carve(const kvc_params* p, int n_items = 1) {
         // (H2O exact, fused form: the same region holds the permuted copy of K, [bsz * Hkv][L][D])
         const size_t h2o_kt = (size_t)p->bsz * p->n_kv_heads * ((L + 15) / 16 * 16) * p->head_dim * es;
         const size_t h2o_s = heads * (size_t)l.h2o_rows * L * es;
-        l.logits = off; off = align_up(off + (p->method == KVC_H2O ? (h2o_fast ? 0 : (h2o_s > h2o_kt ? h2o_s : h2o_kt)) : heads * L * R * es), 256);
+        const bool h2o_fused = p->method == KVC_H2O && !h2o_fast && kvc::h2o_fused_eligible(p->dtype, (int)L, (p->debug_stage_mask & 2048) ? 1 : 0);
+        l.logits = off; off = align_up(off + (p->method == KVC_H2O ? (h2o_fast ? 0 : (h2o_fused ? h2o_kt : h2o_s)) : heads * L * R * es), 256);
         l.pmax = off;   off = align_up(off + (p->method == KVC_H2O ? 0 : heads * (size_t)l.n_tiles * W * 4), 256);
         // H2O: column sums of every 256-row block (+ one slot for the leftover rows), fp32, columns padded to even
         l.psum = off;   off = align_up(off + ((p->method == KVC_H2O && !h2o_fast) ? heads * (size_t)(l.n_chunks + 1) * ((n + 1) & ~(size_t)1) * 4 : 0), 256);

@@ -820,6 +820,12 @@ __device__ __forceinline__ f32x2 exp_u20x2_nonpos(f32x2 x) {
     p = p * (f32x2)2.0f;
     return p;
 }
+// v_max_f32 as is (fmaxf would canonicalise both operands first: three instructions; no NaN reaches these maxima)
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // One group of four MFMA steps of the fused kernel: A = four fp32 values of the lane's Q row slot, B = four bf16 elements of
 // the lane's 16-byte K chunk widened by the load (kvc_ldsasm.h).  5 LDS reads; retired by wait_step.
 template <int QOFF, int KOFF> __device__ __forceinline__ void fz_ld(f32x4& A, uint32_t (&B)[4], uint32_t q_a, uint32_t k_a) {
@@ -883,7 +889,11 @@ __global__ __launch_bounds__(FZ_THREADS) void h2o_fused_kernel(const H2OArgs a) 
     // 16 bytes land at M0 + 16 l), FZ_RING - 2 chunks ahead of the MFMAs that use them.  vmcnt: these loads are the wave's only
     // vector-memory operations in phase A and complete in order.
     auto tile_src = [&](int i) {                                             // (scalar) tile 16 i + wave of the stream, clamped
+#ifdef KVC_FZ_EXP1
+        const int t = wave + 0 * i;                                          // (timing experiment: K always from the same 16 tiles)
+#else
         const int t = 16 * i + wave;
+#endif
         return ktb + (uint64_t)(t < n_tiles ? t : n_tiles - 1) * (KV4 * 1024);
     };
     for (int sb = 0; sb < 16; ++sb) {
@@ -985,8 +995,8 @@ __global__ __launch_bounds__(FZ_THREADS) void h2o_fused_kernel(const H2OArgs a) 
                     }
                 }
                 // (rounding is monotone: the maximum of the rounded logits is the rounded maximum — rmax is rounded once, below)
-                rmax[0] = __builtin_fmaxf(rmax[0], z01.x); rmax[1] = __builtin_fmaxf(rmax[1], z01.y);
-                rmax[2] = __builtin_fmaxf(rmax[2], z23.x); rmax[3] = __builtin_fmaxf(rmax[3], z23.y);
+                rmax[0] = vmax(rmax[0], z01.x); rmax[1] = vmax(rmax[1], z01.y);
+                rmax[2] = vmax(rmax[2], z23.x); rmax[3] = vmax(rmax[3], z23.y);
                 w01 = pack2<DT>(z01); w23 = pack2<DT>(z23);
             } else {
                 float x[4];
@@ -1029,7 +1039,7 @@ __global__ __launch_bounds__(FZ_THREADS) void h2o_fused_kernel(const H2OArgs a) 
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const f32x4 u = mp[q4];
-                    t = u[0] > t ? u[0] : t; t = u[1] > t ? u[1] : t; t = u[2] > t ? u[2] : t; t = u[3] > t ? u[3] : t;
+                    t = vmax(vmax(t, u[0]), vmax(u[1], vmax(u[2], u[3])));
                 }
                 m[v] = t;
             }
@@ -1049,13 +1059,15 @@ __global__ __launch_bounds__(FZ_THREADS) void h2o_fused_kernel(const H2OArgs a) 
                     f32x2 e01 = exp_u20x2_nonpos(f32x2{wide_lo<DT>(w01), wide_hi<DT>(w01)} + nm01);
                     f32x2 e23 = exp_u20x2_nonpos(f32x2{wide_lo<DT>(w23), wide_hi<DT>(w23)} + nm23);
                     const int t0 = 16 * (16 * i + wave);
-                    if (t0 + 16 > L) {                                       // (uniform) keys beyond L add nothing
-                        const bool kvalid = t0 + n < L;
-                        e01.x = kvalid ? e01.x : 0.0f; e01.y = kvalid ? e01.y : 0.0f;
-                        e23.x = kvalid ? e23.x : 0.0f; e23.y = kvalid ? e23.y : 0.0f;
-                    }
                     float* const dst = eb + (u * 16 + wave) * 256 + lane;
-                    dst[0] = e01.x; dst[64] = e01.y; dst[128] = e23.x; dst[192] = e23.y;
+                    if (__builtin_expect(t0 + 16 > L, 0)) {                  // (uniform, a real branch) keys beyond L add nothing
+                        const bool kvalid = t0 + n < L;
+                        asm volatile("" ::: "memory");
+                        dst[0] = kvalid ? e01.x : 0.0f; dst[64] = kvalid ? e01.y : 0.0f;
+                        dst[128] = kvalid ? e23.x : 0.0f; dst[192] = kvalid ? e23.y : 0.0f;
+                    } else {
+                        dst[0] = e01.x; dst[64] = e01.y; dst[128] = e23.x; dst[192] = e23.y;
+                    }
                 }
             }
             __syncthreads();      // this round's exponentials are in the ring; the chain waves finished the previous round's half
@@ -1090,9 +1102,11 @@ __global__ __launch_bounds__(FZ_THREADS) void h2o_fused_kernel(const H2OArgs a) 
             uint32_t w01, w23;
             s_get(i, w01, w23);
             const int t0 = 16 * (16 * i + wave), key = t0 + n;
+            const float a1v = a1s[key];                                      // (key < FZ_MAX_L always; read ahead of its use)
             f32x2 p01 = round2<DT>(exp_u20x2_nonpos(f32x2{wide_lo<DT>(w01), wide_hi<DT>(w01)} + nm01) * ri01);
             f32x2 p23 = round2<DT>(exp_u20x2_nonpos(f32x2{wide_lo<DT>(w23), wide_hi<DT>(w23)} + nm23) * ri23);
-            if (t0 + 16 > L || !complete) {                                  // (uniform) rows / keys beyond L add nothing
+            if (__builtin_expect(t0 + 16 > L || !complete, 0)) {             // (uniform, a real branch) rows / keys beyond L add nothing
+                asm volatile("" ::: "memory");
                 const bool kvalid = key < L;
                 p01.x = (kvalid && rb + gq < L) ? p01.x : 0.0f; p01.y = (kvalid && rb + 4 + gq < L) ? p01.y : 0.0f;
                 p23.x = (kvalid && rb + 8 + gq < L) ? p23.x : 0.0f; p23.y = (kvalid && rb + 12 + gq < L) ? p23.y : 0.0f;
@@ -1104,7 +1118,7 @@ __global__ __launch_bounds__(FZ_THREADS) void h2o_fused_kernel(const H2OArgs a) 
             cs = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, p23.y, cs, 0, 0, 0);
             const float a0 = cs[0];                                          // the 16-row sum of column `key` (every lane group holds a copy)
             if (complete) {
-                if (gq == 0) a1s[key] = a1s[key] + a0;
+                if (gq == 0) a1s[key] = a1v + a0;
             } else if (gq == 0 && key < ncol) {
                 left[key] = a0;                                              // rows beyond the last full 16-row chunk stay in a0
             }
@@ -1135,6 +1149,10 @@ int h2o_chunk_rows(int heads, int L, int esize) {
     return rows >= (size_t)L ? L : (int)rows;
 }
 
+// The exact mode runs as the fused kernel (no logit matrix in the workspace, only the permuted copy of K) for 16-bit dtypes up
+// to FZ_MAX_L keys unless debug_stage_mask bit 11 asks for round 2's kernels.  The workspace layout (kvc_api.hip) asks the same question.
+bool h2o_fused_eligible(int dtype, int L, int legacy) { return dtype != KVC_FP32 && !legacy && L >= 16 && L <= FZ_MAX_L; }
+
 template <int DT, int D>
 static int launch_h2o_t(const H2OArgs& a0, hipStream_t st) {
     constexpr int ES = Dt<DT>::esize;
@@ -1152,7 +1170,7 @@ static int launch_h2o_t(const H2OArgs& a0, hipStream_t st) {
     bool wide = false;
     if constexpr (DT != KVC_FP32) wide = (L % 8) == 0 && (a.window % 2) == 0 && L >= 16;
     if constexpr (DT != KVC_FP32) {
-        if (!a.legacy && a.part && a.kt && L >= 16 && L <= FZ_MAX_L) {
+        if (h2o_fused_eligible(DT, L, a.legacy) && a.part && a.kt) {
             const size_t lds_f = fz_lds_bytes(D);
             static LdsCache c_f = {};
             if (ensure_lds(reinterpret_cast<const void*>(&h2o_fused_kernel<DT, D>), lds_f, c_f) != 0) return KVC_ERR_HIP;

@@ -178,7 +178,8 @@ inline int ensure_lds(const void* func, size_t lds, LdsCache& cache) {
 
 int launch_scores(const ScoreArgs& a, int dtype, int head_dim, hipStream_t st);
 int launch_h2o_scores(const H2OArgs& a, int dtype, int head_dim, hipStream_t st);
-int h2o_chunk_rows(int heads, int L, int esize);   // query rows of the exact mode's logit matrix held at a time
+int h2o_chunk_rows(int heads, int L, int esize);
+bool h2o_fused_eligible(int dtype, int L, int legacy);   // exact mode: the one-kernel form applies (workspace: permuted K instead of S)   // query rows of the exact mode's logit matrix held at a time
 int launch_select(const SelectArgs& a, int dtype, int tie_mode, hipStream_t st);
 size_t select_lds_bytes(int k);
 int launch_select_exact(const SelectArgs& a, int dtype, void* scratch, hipStream_t st);   // tie_mode torch_cpu

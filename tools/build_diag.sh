@@ -8,6 +8,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 case "$1" in
   noearlyclobber) FLAG=-DKVC_DIAG_NO_EARLYCLOBBER ;;
   stamps) FLAG=-DKVC_STAMPS ;;
+  stamps_exp1) FLAG="-DKVC_STAMPS -DKVC_FZ_EXP1" ;;
   *) echo "usage: $0 noearlyclobber|stamps"; exit 2 ;;
 esac
 B=$(mktemp -d)
