@@ -753,14 +753,16 @@ constexpr int FZ_EBUF = 32 * 4 * 64;                         // floats per ring 
 constexpr int FZ_RING = 4;                                   // 1 KB chunks of K per wave in LDS (phase A)
 constexpr size_t fz_lds_bytes(int D) {
     const size_t x = (size_t)2 * FZ_EBUF * 4, r = (size_t)FZ_WAVES * FZ_RING * 1024;
-    return (size_t)(16 * (D + 4) + 256 + 16 + FZ_MAX_L) * 4 + (x > r ? x : r);
+    return (size_t)(16 * D + 256 + 16 + FZ_MAX_L) * 4 + (x > r ? x : r);
 }
 
 // The B operand of lane (key n, k-slot gq) over a tile's D / 4 steps is K[key][gq], K[key][4 + gq], ...: 2-byte elements 8 bytes
-// apart.  h2o_kperm_kernel lays K out as the waves will load it: Kt[b][g][tile][chunk c][lane = 16 gq + n] = the 16 bytes
-// {K[16 tile + n][4 s + gq] : s = 8 c .. 8 c + 7} — one global_load_dwordx4 of a wave reads 1 KB of contiguous memory
-// (a first version kept the permutation inside each 256-byte row: every load touched all 32 cache lines of the tile and the
-// kernel was bound by L1 refills).  Keys beyond L are zeros.  grid = (ceil(tiles * D/8 * 16 / 256), bsz * n_kv_heads), block = 256.
+// apart.  h2o_kperm_kernel lays K out as the fused kernel's LDS wants it, in 1 KB chunks that global_load_lds_dwordx4 copies
+// verbatim: Kt[b][g][tile][chunk c] = u16 [8 steps e][64 lanes], entry (e, lane = 16 gq + n) = K[16 tile + n][4 (8 c + e) + gq].
+// Element-major, so that one ds_read_u16_d16_hi of a wave reads 128 contiguous bytes — all 32 banks, two lanes per dword.
+// (A lane-major chunk, lane l's eight steps in 16 contiguous bytes, put the 64 lanes of a read on 8 banks: with the Q
+// operand's conflicts the LDS, not the matrix core, bounded the logits phase.)  Keys beyond L are zeros.
+// grid = (ceil(tiles * D/32 * 64 / 256), bsz * n_kv_heads), block = 256: one 16-byte piece (8 lanes of one step) per thread.
 template <int DT, int D>
 __global__ __launch_bounds__(256) void h2o_kperm_kernel(const H2OArgs a) {
     typedef typename Dt<DT>::raw raw;
@@ -768,13 +770,15 @@ __global__ __launch_bounds__(256) void h2o_kperm_kernel(const H2OArgs a) {
     const int L = a.q_len, n_tiles = (L + 15) / 16, bg = blockIdx.y, b = bg / a.n_kv_heads, g = bg % a.n_kv_heads;
     const int o = blockIdx.x * 256 + threadIdx.x;                             // output uint4 index within the head
     if (o >= n_tiles * KV4 * 64) return;
-    const int lane = o & 63, c = (o >> 6) % KV4, tile = (o >> 6) / KV4, n = lane & 15, gq = lane >> 4, key = 16 * tile + n;
-    uint32_t w[4] = {0, 0, 0, 0};
-    if (key < L) {
-        const raw* kr = reinterpret_cast<const raw*>(a.k) + (int64_t)b * a.k_stride_b + (int64_t)g * a.k_stride_h + (int64_t)key * a.k_stride_l;
+    const int p16 = o & 63, c = (o >> 6) % KV4, tile = (o >> 6) / KV4;
+    const int e = p16 >> 3, gq = (p16 & 7) >> 1, n0 = 8 * (p16 & 1), dim = 4 * (8 * c + e) + gq;
+    const raw* kh = reinterpret_cast<const raw*>(a.k) + (int64_t)b * a.k_stride_b + (int64_t)g * a.k_stride_h + dim;
+    uint32_t w[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            w[e] = (uint32_t)kr[4 * (8 * c + 2 * e) + gq] | ((uint32_t)kr[4 * (8 * c + 2 * e + 1) + gq] << 16);
+    for (int jj = 0; jj < 4; ++jj) {
+        const int k0 = 16 * tile + n0 + 2 * jj, k1 = k0 + 1;
+        const uint32_t lo = k0 < L ? (uint32_t)kh[(int64_t)k0 * a.k_stride_l] : 0u, hi = k1 < L ? (uint32_t)kh[(int64_t)k1 * a.k_stride_l] : 0u;
+        w[jj] = lo | (hi << 16);
     }
     reinterpret_cast<uint4*>(a.kt)[(int64_t)bg * n_tiles * KV4 * 64 + o] = make_uint4(w[0], w[1], w[2], w[3]);
 }
@@ -826,8 +830,9 @@ __device__ __forceinline__ float vmax(float a, float b) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-// One group of four MFMA steps of the fused kernel: A = four fp32 values of the lane's Q row slot, B = four bf16 elements of
-// the lane's 16-byte K chunk widened by the load (kvc_ldsasm.h).  5 LDS reads; retired by wait_step.
+// One group of four MFMA steps of the fused kernel: A = the group's 16 bytes of the lane's Q fragment (image: [group][lane][4] fp32),
+// B = the lane's bf16 element of four consecutive steps of the K chunk ([step][lane] u16), widened by the load (kvc_ldsasm.h).
+// Every one of the 5 reads touches each LDS bank once.  Retired by wait_step.
 template <int QOFF, int KOFF> __device__ __forceinline__ void fz_ld(f32x4& A, uint32_t (&B)[4], uint32_t q_a, uint32_t k_a) {
     asm volatile("ds_read_b128 %0, %5 offset:%7\n\t"
                  "ds_read_u16_d16_hi %1, %6 offset:%8\n\t"
@@ -835,20 +840,20 @@ template <int QOFF, int KOFF> __device__ __forceinline__ void fz_ld(f32x4& A, ui
                  "ds_read_u16_d16_hi %3, %6 offset:%10\n\t"
                  "ds_read_u16_d16_hi %4, %6 offset:%11"
                  : KVC_LD_OUT(A), KVC_LD_OUT(B[0]), KVC_LD_OUT(B[1]), KVC_LD_OUT(B[2]), KVC_LD_OUT(B[3])
-                 : "v"(q_a), "v"(k_a), "n"(QOFF), "n"(KOFF), "n"(KOFF + 2), "n"(KOFF + 4), "n"(KOFF + 6)
+                 : "v"(q_a), "v"(k_a), "n"(QOFF), "n"(KOFF), "n"(KOFF + 128), "n"(KOFF + 256), "n"(KOFF + 384)
                  : "memory");
 }
 
 // grid = bsz * n_q_heads * ceil(L / 256), block = 1024.
-// LDS: Q operand [16][D + 4] f32, maxima [16][16], rinv [16], a1 [8192], then the K rings (phase A) / the exponentials' ring (phase C).
+// LDS: Q operand image [D / 16][64][4] f32, maxima [16][16], rinv [16], a1 [8192], then the K rings (phase A) / the exponentials' ring (phase C).
 template <int DT, int D>
 __global__ __launch_bounds__(FZ_THREADS) void h2o_fused_kernel(const H2OArgs a) {
     typedef typename Dt<DT>::raw raw;
-    constexpr int NS = D / 4, KV4 = NS * 2 / 16, QP = D + 4, NG = NS / 4;       // NG groups of four MFMA steps per tile
+    constexpr int NS = D / 4, KV4 = NS * 2 / 16, NG = NS / 4;                  // NG groups of four MFMA steps per tile
     static_assert(FZ_RING % KV4 == 0 && FZ_RING - 1 <= 2 * KV4, "ring slots follow the tile's chunks");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const qs = reinterpret_cast<float*>(smem);
-    float* const mx = qs + 16 * QP;
+    float* const mx = qs + 16 * D;                                          // (Q image: [NG][64 lanes][4] fp32)
     float* const rinvs = mx + 256;
     float* const a1s = rinvs + 16;                                           // [FZ_MAX_L] the block's a1 per key
     float* const ebuf = a1s + FZ_MAX_L;                                      // phase C: the exponentials' ring; phase A: the K rings
@@ -907,8 +912,8 @@ __global__ __launch_bounds__(FZ_THREADS) void h2o_fused_kernel(const H2OArgs a) 
             const raw* qr = qb + (int64_t)row * a.q_stride_l + (tid & 63) * EPT;
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
-                const int d = (tid & 63) * EPT + e;
-                qs[slot * QP + (d & 3) * NS + (d >> 2)] = Dt<DT>::ld(qr[e]);
+                const int d = (tid & 63) * EPT + e, st_ = d >> 2;             // step st_, k-slot d & 3: group st_ >> 2, lane 16 (d & 3) + slot
+                qs[((st_ >> 2) * 64 + (d & 3) * 16 + slot) * 4 + (st_ & 3)] = Dt<DT>::ld(qr[e]);
             }
         }
         __syncthreads();
@@ -920,14 +925,16 @@ __global__ __launch_bounds__(FZ_THREADS) void h2o_fused_kernel(const H2OArgs a) 
             constexpr int coff = decltype(coff_)::value;
             const uint32_t dst = ring_base + slot * 1024u;
             // (an instruction offset would move the LDS destination as well as the source: the chunk offset goes into the scalar base)
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(lane16), "s"(sp + (uint64_t)(coff * 1024)) : "memory", "m0");
+            // hipcc pads nothing inside the string: the scalar base may come straight from an s_add (SALU write -> VMEM read of
+            // the SGPR: 5 wait states) and M0 is written right before the load that reads it (1 wait state).
+            asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(lane16), "s"(sp + (uint64_t)(coff * 1024)) : "memory", "m0");
         };
         static_for<0, FZ_RING - 1>([&](auto q_) {
             constexpr int q = decltype(q_)::value;
             kdma(src[q / KV4], std::integral_constant<int, q % KV4>{}, (uint32_t)q);
         });
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FZ_RING - 2) : "memory");  // chunk 0 has landed
-        const uint32_t q_a = lds_addr(qs + n * QP + gq * NS), k_a0 = lds_addr(ring) + lane * 16;
+        const uint32_t q_a = lds_addr(qs) + lane * 16, k_a0 = lds_addr(ring) + lane * 2;
         for (int i = 0; i < tpw; ++i) {
             const uint32_t ring_i = (uint32_t)((i * KV4) % FZ_RING);          // slot of this tile's chunk 0 (uniform)
             const uint32_t k_a = k_a0 + ring_i * 1024u;
@@ -946,7 +953,7 @@ __global__ __launch_bounds__(FZ_THREADS) void h2o_fused_kernel(const H2OArgs a) 
                         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FZ_RING - 2) : "memory");
                     }
                     if constexpr (g + 1 < NG) {
-                        fz_ld<16 * (g + 1), ((g + 1) / 2) * 1024 + ((g + 1) & 1) * 8>((g & 1) ? A0 : A1, (g & 1) ? B0 : B1, q_a, k_a);
+                        fz_ld<1024 * (g + 1), ((g + 1) / 2) * 1024 + ((g + 1) & 1) * 512>((g & 1) ? A0 : A1, (g & 1) ? B0 : B1, q_a, k_a);
                         wait_step<5>(Ac, Bc);
                     } else {
                         wait_step<0>(Ac, Bc);
@@ -955,20 +962,26 @@ __global__ __launch_bounds__(FZ_THREADS) void h2o_fused_kernel(const H2OArgs a) 
                     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ac[e], u2f(Bc[e]), acc, 0, 0, 0);
                 });
             } else {
-                const float* const qrow = qs + n * QP + gq * NS;
                 static_for<0, KV4>([&](auto c_) {
                     constexpr int c = decltype(c_)::value, ahead = c + FZ_RING - 1;
                     kdma(src[ahead / KV4], std::integral_constant<int, ahead % KV4>{}, (ring_i + (uint32_t)ahead) % FZ_RING);
-                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FZ_RING - 1) : "memory");   // chunk q has landed
-                    const uint4 kv = *reinterpret_cast<const uint4*>(ring + ((ring_i + c) % FZ_RING) * 1024 + lane * 16);
+                    // chunk q has landed.  The lane's offset is an operand of the wait: hipcc moved plain LDS loads ABOVE an asm wait
+                    // that only clobbers "memory" (seen in the listing; run-to-run different fp16 scores) — a data dependence it keeps.
+                    uint32_t koff = lane * 2;
+                    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(koff) : "n"(FZ_RING - 1) : "memory");
+                    const raw* const kc = reinterpret_cast<const raw*>(ring + ((ring_i + c) % FZ_RING) * 1024 + koff);
+                    uint32_t kr[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) kr[e] = kc[e * 64];
+                    // ... and the chunk's reads are RETIRED here, as operands of the wait: the next step's DMA overwrites this slot,
+                    // and hipcc had placed that DMA right behind the issue of these reads (write-after-read on a busy LDS).
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kr[0]), "+v"(kr[1]), "+v"(kr[2]), "+v"(kr[3]), "+v"(kr[4]), "+v"(kr[5]), "+v"(kr[6]), "+v"(kr[7]) :: "memory");
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const f32x4 qv = *reinterpret_cast<const f32x4*>(qrow + 8 * c + 4 * h);
-                        const uint32_t w0 = h ? kv.z : kv.x, w1 = h ? kv.w : kv.y;
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[0], wide_lo<DT>(w0), acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[1], wide_hi<DT>(w0), acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[2], wide_lo<DT>(w1), acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[3], wide_hi<DT>(w1), acc, 0, 0, 0);
+                        const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + ((2 * c + h) * 64 + lane) * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[e], Dt<DT>::ld((raw)kr[4 * h + e]), acc, 0, 0, 0);
                     }
                 });
             }
