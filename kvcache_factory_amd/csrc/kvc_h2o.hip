@@ -798,32 +798,6 @@ template <int DT> __device__ __forceinline__ uint32_t pack2(f32x2 v) {
         return (uint32_t)Dt<DT>::st(v.x) | ((uint32_t)Dt<DT>::st(v.y) << 16);
     }
 }
-// exp_u20x2 for arguments <= 0 (logit minus its row maximum), bit-identical to it there with 10 instructions fewer: no
-// upper clamp; the clamped input ln(FLT_MIN) yields fx = -126 and so 2^n = bits 0 = +0.0 — what the `below` select of
-// exp_u20x2 returns — and (int)(fx - 1) + 127 = (int)fx + 126 because fx is integral.  (An argument > 0 or NaN can
-// only come from a query row beyond L, whose results are discarded.)
-__device__ __forceinline__ f32x2 exp_u20x2_nonpos(f32x2 x) {
-    const float ln_flt_min = u2f(0xc2aeac50u);
-    const f32x2 log2ef = u2f(0x3fb8aa3bu), nln2f = -u2f(0x3f317218u);
-    const f32x2 c1 = 0.999999701f, c2 = 0.499991506f, c3 = 0.166676521f, c4 = 0.0418978221f, c5 = 0.00828929059f;
-    f32x2 s_;
-    s_.x = (x.x > ln_flt_min) ? x.x : ln_flt_min;
-    s_.y = (x.y > ln_flt_min) ? x.y : ln_flt_min;
-    f32x2 fx = __builtin_elementwise_fma(s_, log2ef, (f32x2)0.5f);
-    fx.x = __builtin_floorf(fx.x); fx.y = __builtin_floorf(fx.y);
-    const f32x2 r = __builtin_elementwise_fma(fx, nln2f, s_);
-    f32x2 p = __builtin_elementwise_fma(r, c5, c4);
-    p = __builtin_elementwise_fma(r, p, c3);
-    p = __builtin_elementwise_fma(r, p, c2);
-    p = __builtin_elementwise_fma(r, p, c1);
-    p = __builtin_elementwise_fma(r, p, (f32x2)1.0f);
-    f32x2 two_n;
-    two_n.x = u2f((uint32_t)((int)fx.x + 126) << 23);
-    two_n.y = u2f((uint32_t)((int)fx.y + 126) << 23);
-    p = p * two_n;
-    p = p * (f32x2)2.0f;
-    return p;
-}
 // v_max_f32 as is (fmaxf would canonicalise both operands first: three instructions; no NaN reaches these maxima)
 __device__ __forceinline__ float vmax(float a, float b) {
     float r;

@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(256) void pool_kernel(const ScoreArgs a) {
             for (int w = 0; w < (WV > 0 ? WV : W); ++w) {
                 if constexpr (WV > 0) {
                     if ((w & 1) == 0) {
-                        const f32x2 pr = exp_u20x2(f32x2{x[w], x[w + 1]} - f32x2{m[w], m[w + 1]}) * f32x2{rinv[w], rinv[w + 1]};
+                        const f32x2 pr = exp_u20x2_nonpos(f32x2{x[w], x[w + 1]} - f32x2{m[w], m[w + 1]}) * f32x2{rinv[w], rinv[w + 1]};
                         x[w] = pr.x; x[w + 1] = pr.y;
                     }
                     cs.add(rnd<DT>(x[w]));
@@ -1165,7 +1165,7 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
             const int key = it * SP_THREADS + tid;
 #pragma unroll
             for (int w = 0; w < W; w += 2) {
-                const f32x2 ex = exp_u20x2(f32x2{x[it][w], x[it][w + 1]} - f32x2{mr[w], mr[w + 1]});
+                const f32x2 ex = exp_u20x2_nonpos(f32x2{x[it][w], x[it][w + 1]} - f32x2{mr[w], mr[w + 1]});
                 e[it][w] = (it < iters && key < L) ? ex.x : 0.0f; e[it][w + 1] = (it < iters && key < L) ? ex.y : 0.0f;
             }
         }
@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
                 load_logits<DT, W>(lg + (int64_t)key * W, W, x);
 #pragma unroll
                 for (int ww = 0; ww < W; ww += 2) {
-                    const f32x2 ex = exp_u20x2(f32x2{x[ww], x[ww + 1]} - f32x2{mr[ww], mr[ww + 1]});
+                    const f32x2 ex = exp_u20x2_nonpos(f32x2{x[ww], x[ww + 1]} - f32x2{mr[ww], mr[ww + 1]});
                     x[ww] = ex.x; x[ww + 1] = ex.y;
                 }
                 have = it;
@@ -1307,7 +1307,7 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_kernel(const ScoreArg
                     load_logits<DT, W>(lg + (int64_t)key * W, W, x);
 #pragma unroll
                     for (int w = 0; w < W; w += 2) {
-                        const f32x2 ex = exp_u20x2(f32x2{x[w], x[w + 1]} - f32x2{mr[w], mr[w + 1]});
+                        const f32x2 ex = exp_u20x2_nonpos(f32x2{x[w], x[w + 1]} - f32x2{mr[w], mr[w + 1]});
                         ev[w] = ex.x; ev[w + 1] = ex.y;
                     }
                     sv = window_sum(ev);
@@ -1383,7 +1383,7 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_ws_kernel(const Score
             widen_logits<DT, W>(rawx[it], x);
 #pragma unroll
             for (int w = 0; w < W; w += 2) {
-                const f32x2 ex = exp_u20x2(f32x2{x[w], x[w + 1]} - f32x2{mr[w], mr[w + 1]});
+                const f32x2 ex = exp_u20x2_nonpos(f32x2{x[w], x[w + 1]} - f32x2{mr[w], mr[w + 1]});
                 e[it][w] = (worker && key < L) ? ex.x : 0.0f; e[it][w + 1] = (worker && key < L) ? ex.y : 0.0f;
             }
             float* buf = stage + (it & 1) * ESTAGE;

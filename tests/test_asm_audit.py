@@ -87,6 +87,20 @@ def test_h2o_kernel_asm_loads_are_clean(h2o_audit):
         assert stats["ScratchSize"] == 0
 
 
+def test_h2o_fused_kernel_asm_loads_are_clean(h2o_audit):
+    """h2o_fused_kernel<bf16, D> (round 3): its MFMA operands come from hand-issued ds_read_b128 / ds_read_u16_d16_hi out of an
+    image that hand-issued global_load_lds statements fill.  Between a load block and its wait: MFMAs and scalar
+    instructions only; 124-128 VGPRs (16 waves per CU hold 16 query rows of the logit matrix in registers) and no scratch
+    at all — one spilled vector of logits inside the tile loop cost 8 scratch loads and stores per tile in the first build."""
+    ks = {k: v for k, v in h2o_audit.items() if "h2o_fused_kernelILi0E" in k}
+    assert len(ks) == 2, sorted(ks)                     # bf16, D = 128 and 64
+    for name, (problems, stats) in ks.items():
+        assert not problems, (name, problems[:5])
+        d = 128 if "Li128E" in name else 64
+        assert stats["asm_load_blocks"] == stats["asm_wait_blocks"] == d // 16 and stats["asm_loads"] == 5 * (d // 16)
+        assert stats["NumVgprs"] <= 128 and stats["ScratchSize"] == 0 and stats["Occupancy"] == 4
+
+
 def test_audit_sees_round1_hazard():
     """The same H2O kernel built with plain "=v" outputs (-DKVC_DIAG_NO_EARLYCLOBBER): hipcc gives the last step's first
     destination the address register (`ds_read_u16_d16_hi vN, vN` followed by loads addressed through vN) — the cause

@@ -41,4 +41,8 @@ grep "kvc::\|^\"Name\|attention\|fmha\|Cijk\|cat\|index" /tmp/kt_dec/*/*_kernel_
 rm -rf /tmp/kt_n2 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_n2 -- python3 $R/tools/n2_probe.py > $OUT/${TAG}_n2_probe.log 2>&1
 head -25 /tmp/kt_n2/*/*_kernel_stats.csv > $OUT/${TAG}_n2_kernel_stats.csv
 (cd $R/tools && for p in hop_probe step_probe; do [ -x ./$p ] && ./$p > $OUT/${TAG}_$p.txt 2>&1; done; [ -x ./heap_probe ] && ./heap_probe 7992 120 260 > $OUT/${TAG}_heap_probe.txt 2>&1)
+# 5. round 3: the matrix-core probes behind h2o_fused_kernel (16x16x4 f32 accumulation order; sustained f32 MFMA rate), its phase shares
+(cd $R/tools && for p in mfma16x4_probe mfma_peak_probe; do [ -x ./$p ] && ./$p > $OUT/${TAG}_$p.txt 2>&1; done)
+[ -f $R/tools/diag/libkvc_hip_stamps.so ] && KVC_LIB_PATH=$R/tools/diag/libkvc_hip_stamps.so python3 $R/tools/h2o_fused_stamps.py > $OUT/${TAG}_h2o_fused_stamps.txt 2>&1
+(cd $R && python3 bench.py --config c3 --steps 5 --warmup 2 > $OUT/${TAG}_bench_c3_exact.json 2> /dev/null; python3 bench.py --steps 30 --warmup 5 > $OUT/${TAG}_bench_c2.json 2> /dev/null)
 ls -la $OUT
