@@ -209,13 +209,13 @@ def kernel_breakdown(prompt, dev, tie_mode, reps=10):
     return out
 
 
-def pmc_traffic(kernel_prefix, tag="r03"):
+def pmc_traffic(kernel_prefix, tag="r03", cfgname=None):
     """HBM bytes per launch of one kernel from the committed PMC passes (profiles/<tag>_pmc_batch_*.csv; separate
     rocprofv3 --pmc runs of tools/prof_driver.py; FETCH_SIZE doubled per the gfx950 correction).  None if absent."""
     import csv
 
     def one(name):
-        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_batch_{name}.csv")
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_batch_{cfgname + '_' if cfgname else ''}{name}.csv")
         with open(path) as fh:
             return [float(r["mean_per_dispatch"]) for r in csv.DictReader(fh)
                     if r["kernel"].startswith(kernel_prefix) and r["counter"] == name][0]
@@ -411,11 +411,24 @@ def main():
         out["path_frac"] = path_b / t_layer / 1e9 / HBM_PEAK_GBS
         if h2o:
             flops = 2.0 * HQ * cfg["L"] * cfg["L"] * D       # one QK^T per layer
-            out["roofline"] = {"bound": "mfma", "kernel": "h2o scoring kernels (logits + row / column softmax sums)",
+            exact = a.dot_mode == "exact"
+
+            def pmc_c3(prefixes):
+                vals = [pmc_traffic(p_, tag="r03", cfgname="c3") for p_ in prefixes]
+                return None if any(v is None for v in vals) else sum(vals)
+            out["roofline"] = {"bound": "mfma", "kernel": "h2o_fused_kernel (logits, torch-order softmax sums and column sums in one kernel)"
+                               if exact else "h2o_fast_stats_kernel + h2o_fast_colsum_kernel",
                                "achieved": flops / t_layer / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": flops / t_layer / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
+                               "frac": flops / t_layer / 1e12 / MFMA_PEAK_TFLOPS,
+                               "traffic": pmc_c3(["kvc::h2o_fused_kernel", "kvc::h2o_kperm_kernel", "kvc::h2o_colcomb_kernel"]) if exact else None,
+                               "traffic_source": "profiles/r03_pmc_batch_c3_{FETCH,WRITE}_SIZE.csv: permute + fused + combine kernels of one layer "
+                                                 "(FETCH_SIZE x2 gfx950 correction); algorithmic inputs Q + K = 82 MB",
                                "launch_us": t_layer * 1e6, "algorithmic_flops_per_layer": flops,
-                               "note": "exact arithmetic: f32-input MFMA (157 TF peak), scored against the bf16 MFMA peak"}
+                               "note": "scored against the bf16 MFMA peak as BASELINE's metric asks; the exact mode computes on the f32-input "
+                                       "MFMA (mfma_f32_* fields), which shares its SIMD's issue time with VALU work (DESIGN.md section 4)"}
+            if exact:
+                out["roofline"].update({"mfma_f32_TFLOPs": flops / t_layer / 1e12, "mfma_f32_peak_TFLOPs": MFMA_F32_PEAK_TFLOPS,
+                                        "mfma_f32_frac": flops / t_layer / 1e12 / MFMA_F32_PEAK_TFLOPS})
         elif a.mode == "batch":
             kt = kernel_breakdown(prompts[0], dev, a.tie_mode)
             tot = sum(kt.values())
