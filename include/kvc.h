@@ -105,7 +105,9 @@ typedef struct kvc_params {
                                   kernel instead of the four-waves-share-a-tile one (identical results).  Bit10 (measurement): at window 8 the
                                   one-workgroup-per-head softmax stage without its chain-wave / worker-wave split (identical results).
                                   Bit11 (H2O exact mode, testing): round 2's kernels that write the logit matrix to the
-                                  workspace instead of the fused one that keeps 16 query rows of it in registers (identical results). */
+                                  workspace instead of the fused one that keeps 16 query rows of it in registers (identical results).
+                                  Bit12 (measurement): at windows 16 / 32 / 64 the one-workgroup-per-head softmax stage that reads the
+                                  logits twice instead of the 16-rows-per-workgroup form that reads them once (identical results). */
     int32_t dot_mode;          /* kvc_dot_mode */
     int64_t q_stride_b, q_stride_h, q_stride_l;   /* element strides of q[b][h][l][:] */
     int64_t k_stride_b, k_stride_h, k_stride_l;

@@ -269,7 +269,7 @@ def scores(method, q, k, window, kernel_size=5, pooling="avgpool", want_intermed
     _require_gpu(q, k)
     q, k = _last_dim_contig(q), _last_dim_contig(k)
     p = make_params(method, q, k, None, window, 0, kernel_size, pooling, dot_mode=dot_mode)
-    p.debug_stage_mask = {None: 0, "split": 8, "fused": 16, "fused_r2": 16 | 1024}[softmax_path] | debug_mask
+    p.debug_stage_mask = {None: 0, "split": 8, "fused": 16, "fused_r2": 16 | 1024 | 4096}[softmax_path] | debug_mask
     bsz, hq, L = q.shape[0], q.shape[1], q.shape[2]
     sc = torch.empty(bsz, hq, L - window, dtype=q.dtype, device=q.device)
     nbytes = lib().kvc_workspace_bytes(ctypes.byref(p))

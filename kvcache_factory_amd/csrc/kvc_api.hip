@@ -30,6 +30,7 @@ struct Layout {
     size_t logits, pmax, psum, rowmax, rowsum, scores, idx, exact, total;   // H2O: logits = S [L][L], rowmax/rowsum = [L] per head
     int n_tiles, n_chunks;
     int h2o_rows;      // H2O exact mode: query rows of S in flight; 0 in fast mode (no S)
+    bool has_part16;   // the psum region holds the window methods' 16-row partial sums
 };
 
 // Validation shared by every entry point.  `need_q`: the call reads q/k for scoring.
@@ -110,7 +111,10 @@ Layout carve(const kvc_params* p, int n_items = 1) {
         l.logits = off; off = align_up(off + (p->method == KVC_H2O ? (h2o_fast ? 0 : (h2o_fused ? h2o_kt : h2o_s)) : heads * L * R * es), 256);
         l.pmax = off;   off = align_up(off + (p->method == KVC_H2O ? 0 : heads * (size_t)l.n_tiles * W * 4), 256);
         // H2O: column sums of every 256-row block (+ one slot for the leftover rows), fp32, columns padded to even
-        l.psum = off;   off = align_up(off + ((p->method == KVC_H2O && !h2o_fast) ? heads * (size_t)(l.n_chunks + 1) * ((n + 1) & ~(size_t)1) * 4 : 0), 256);
+        // window methods at W = 16 / 32 / 64, 16-bit: the 16-row partial window sums of softmax_rows16_kernel, fp32
+        l.has_part16 = p->method != KVC_H2O && p->dtype != KVC_FP32 && (W == 16 || W == 32 || W == 64);
+        l.psum = off;   off = align_up(off + ((p->method == KVC_H2O && !h2o_fast) ? heads * (size_t)(l.n_chunks + 1) * ((n + 1) & ~(size_t)1) * 4
+                                              : (l.has_part16 ? heads * (W / 16) * ((n + 1) & ~(size_t)1) * 4 : 0)), 256);
         l.rowmax = off; off = align_up(off + heads * R * 4, 256);
         l.rowsum = off; off = align_up(off + heads * R * 4, 256);
         l.scores = off; off = align_up(off + heads * n * es, 256);
@@ -179,6 +183,7 @@ int enqueue_scores(const kvc_params* p, const Layout& l, const Items& it, char* 
     a.ws = ws; a.ws_item_stride = (int64_t)l.total;
     a.off_logits = (int64_t)l.logits; a.off_pmax = (int64_t)l.pmax;
     a.off_rowmax = (int64_t)l.rowmax; a.off_rowsum = (int64_t)l.rowsum;
+    a.off_part16 = l.has_part16 ? (int64_t)l.psum : -1;
     a.q_stride_b = p->q_stride_b; a.q_stride_h = p->q_stride_h; a.q_stride_l = p->q_stride_l;
     a.k_stride_b = p->k_stride_b; a.k_stride_h = p->k_stride_h; a.k_stride_l = p->k_stride_l;
     a.bsz = p->bsz; a.n_q_heads = p->n_q_heads; a.n_kv_heads = p->n_kv_heads;

@@ -16,6 +16,7 @@ struct I64Table { int64_t v[KVC_MAX_ITEMS]; };
 struct ScoreView {         // one item's pointers, resolved at kernel entry
     const void* q; const void* k;
     void* logits; float* pmax; float* rowmax; float* rowsum; void* scores;
+    float* part16;         // [bsz*Hq][W/16][n_pad] fp32: in-order sums of 16 window rows (softmax_rows16_kernel), or null
 };
 
 struct ScoreArgs {
@@ -27,6 +28,7 @@ struct ScoreArgs {
     int64_t off_pmax;      // [bsz*Hq][n_tiles][W] fp32
     int64_t off_rowmax;    // [bsz*Hq][W] fp32
     int64_t off_rowsum;    // [bsz*Hq][W] fp32
+    int64_t off_part16;    // [bsz*Hq][W/16][n_pad] fp32, or -1 (window not a multiple of 16, fp32)
     int n_items;
     int64_t q_stride_b, q_stride_h, q_stride_l;
     int64_t k_stride_b, k_stride_h, k_stride_l;

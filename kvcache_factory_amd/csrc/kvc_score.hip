@@ -33,6 +33,7 @@ __device__ __forceinline__ ScoreView view_of(const ScoreArgs& a, int item) {
     v.pmax = reinterpret_cast<float*>(w + a.off_pmax);
     v.rowmax = reinterpret_cast<float*>(w + a.off_rowmax);
     v.rowsum = reinterpret_cast<float*>(w + a.off_rowsum);
+    v.part16 = a.off_part16 >= 0 ? reinterpret_cast<float*>(w + a.off_part16) : nullptr;
     return v;
 }
 
@@ -1469,6 +1470,152 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_pool_ws_kernel(const Score
 }
 
 // ---------------------------------------------------------------------------------------------
+// softmax_rows16_kernel + softmax_comb16_kernel (round 3; W = 16, 32 or 64, 16-bit dtypes, 16 <= L <= 8 192): the logits are
+// read ONCE.  softmax_pool_kernel cannot keep a head's exponentials at these windows (32 rows x 8 keys per thread) and reads
+// the logits a second time for its normalising pass: 1.02 GB fetched for 524 MB of logits at C2 / W = 32 (round 2's PMC pass).
+// The rows of the window are independent until torch's window sum, which is a cascade with 16-row leaves (SumKernel
+// multi_row_sum, level step 16): sum over W rows = (((0 + P0) + P1) + ...) with Pk the in-order sum of rows 16 k .. 16 k + 15.
+// So one workgroup takes 16 ROWS of a head: their logits stay in registers as they arrived (8 keys x 32 bytes per thread),
+// the exponentials are recomputed for the second pass from those registers, and it writes Pk (fp32) to the workspace;
+// softmax_comb16_kernel adds the W / 16 partials in order, rounds, pools and writes the scores.  Same arithmetic in the
+// same order as softmax_pool_kernel (test_softmax_pool_forms_identical); debug_stage_mask bit 12 selects that kernel.
+// The workgroups of one head sit 8 ids apart — on the same XCD, back to back — so the 64-byte (W = 32) key rows they share
+// cache lines of are fetched from HBM once.
+//   rows16: grid = (bsz*n_q_heads * W/16, items), block = 1024, LDS = kSoftmaxLds16.   comb16: grid = (ceil(n / 1024), bsz*n_q_heads, items).
+// ---------------------------------------------------------------------------------------------
+constexpr int R16_ITERS = 8;                                                       // 8 x 1024 keys
+constexpr size_t kSoftmaxLds16 = (size_t)(64 + 64 + 256 + 2 * 16 * EPITCH) * sizeof(float);
+template <int DT>
+__global__ __launch_bounds__(SP_THREADS) void softmax_rows16_kernel(const ScoreArgs a) {
+    const ScoreView vw = view_of(a, blockIdx.y);
+    typedef typename Dt<DT>::raw raw;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, W = a.window, parts = W / 16, heads = a.bsz * a.n_q_heads;
+    int hb, part;
+    if ((heads & 7) == 0) { const int id = blockIdx.x, r = id >> 3; part = r % parts; hb = (r / parts) * 8 + (id & 7); }
+    else { part = blockIdx.x % parts; hb = blockIdx.x / parts; }
+    const int L = a.q_len, n = L - W, n_pad = (n + 1) & ~1;
+    const int iters = (L + SP_THREADS - 1) / SP_THREADS;
+    float* const m = reinterpret_cast<float*>(smem);              // [64]
+    float* const rinv = m + 64;                                   // [64]
+    float* const scratch = rinv + 64;                             // [256]
+    float* const stage = scratch + 256;                           // [2][16][EPITCH]
+    const raw* const lg = reinterpret_cast<const raw*>(vw.logits) + (int64_t)hb * L * W + 16 * part;
+    // the row maxima first: loads return in order, so the maxima would otherwise wait behind the workgroup's 256 KB of logits and
+    // no exponential could start before the last of them had landed; this way iteration 0 computes while 1 .. 7 are in flight
+    block_row_max(vw.pmax + (int64_t)hb * a.n_tiles * W, a.n_tiles, W, m, scratch);
+    uint4 rawx[R16_ITERS][2];
+#pragma unroll
+    for (int it = 0; it < R16_ITERS; ++it) {
+        const int key = it * SP_THREADS + tid;
+        const uint4* src = reinterpret_cast<const uint4*>(lg + (int64_t)(key < L ? key : L - 1) * W);
+        rawx[it][0] = src[0]; rawx[it][1] = src[1];
+    }
+    f32x2 nm[8];                                                  // minus the maxima of this workgroup's rows, in pairs
+#pragma unroll
+    for (int w = 0; w < 8; ++w) nm[w] = f32x2{-m[16 * part + 2 * w], -m[16 * part + 2 * w + 1]};
+    auto exps = [&](const uint4 (&rx)[2], f32x2 (&e)[8]) {
+        const uint32_t wv[8] = {rx[0].x, rx[0].y, rx[0].z, rx[0].w, rx[1].x, rx[1].y, rx[1].z, rx[1].w};
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            f32x2 x;
+            if constexpr (DT == KVC_BF16) x = f32x2{u2f(wv[w] << 16), u2f(wv[w] & 0xffff0000u)};
+            else x = f32x2{Dt<DT>::ld((uint16_t)(wv[w] & 0xffffu)), Dt<DT>::ld((uint16_t)(wv[w] >> 16))};
+            e[w] = exp_u20x2_nonpos(x + nm[w]);
+        }
+    };
+    // pass 1: the denominators in torch's order (16 chains per row, stage by stage: softmax_pool_kernel)
+    const int cw = tid >> 4, cl = tid & 15;                       // tid < 256: chain cl of row cw
+    float acc = 0.0f;
+#pragma unroll
+    for (int it = 0; it < R16_ITERS; ++it) {
+        if (it < iters) {                                          // (uniform)
+            const int key = it * SP_THREADS + tid;
+            f32x2 e[8];
+            exps(rawx[it], e);
+            float* buf = stage + (it & 1) * (16 * EPITCH);
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                buf[(2 * w) * EPITCH + tid] = key < L ? e[w].x : 0.0f;
+                buf[(2 * w + 1) * EPITCH + tid] = key < L ? e[w].y : 0.0f;
+            }
+            __syncthreads();                                       // (the buffer filled two stages ago has been read: its readers passed
+            if (tid < 256)                                         //  the previous barrier after reading)
+                acc = chain16_add(acc, buf + cw * EPITCH + cl, it * SP_THREADS, cl, L);
+        }
+    }
+    const float sum = chain16_fold(acc);
+    if (tid < 256 && cl == 0) {
+        rinv[cw] = 1.0f / sum;
+        vw.rowmax[(int64_t)hb * W + 16 * part + cw] = m[16 * part + cw];
+        vw.rowsum[(int64_t)hb * W + 16 * part + cw] = sum;
+    }
+    __syncthreads();
+    f32x2 ri[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) ri[w] = f32x2{rinv[2 * w], rinv[2 * w + 1]};
+    // pass 2: p = round(e / sum) of the 16 rows added in row order: the cascade's leaf
+    float* const pk = vw.part16 + ((int64_t)hb * parts + part) * n_pad;
+#pragma unroll
+    for (int it = 0; it < R16_ITERS; ++it) {
+        const int key = it * SP_THREADS + tid;
+        if (it < iters && key < n) {
+            f32x2 e[8];
+            exps(rawx[it], e);
+            float a0 = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const f32x2 pr = e[w] * ri[w];
+                a0 = a0 + rnd<DT>(pr.x);
+                a0 = a0 + rnd<DT>(pr.y);
+            }
+            pk[key] = a0;
+        }
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(SP_THREADS) void softmax_comb16_kernel(const ScoreArgs a) {
+    const ScoreView vw = view_of(a, blockIdx.z);
+    typedef typename Dt<DT>::raw raw;
+    __shared__ float seg[SP_THREADS + 64];
+    const int tid = threadIdx.x, hb = blockIdx.y, W = a.window, parts = W / 16;
+    const int L = a.q_len, n = L - W, n_pad = (n + 1) & ~1;
+    const int pad = a.pooling == KVC_POOL_NONE ? 0 : a.kernel_size / 2;       // kernel_size <= 63
+    const int j0 = blockIdx.x * SP_THREADS - pad;                               // seg[i] = key j0 + i
+    const float* const pk = vw.part16 + (int64_t)hb * parts * n_pad;
+    for (int i = tid; i < SP_THREADS + 2 * pad; i += SP_THREADS) {
+        const int key = j0 + i;
+        float v = 0.0f;
+        if (key >= 0 && key < n) {
+            float a1 = 0.0f;                                                    // the cascade's a1: its leaves in order
+            for (int p_ = 0; p_ < parts; ++p_) a1 = a1 + pk[(int64_t)p_ * n_pad + key];
+            v = rnd<DT>(a.window_mean ? a1 / (float)W : a1);
+        }
+        seg[i] = v;
+    }
+    __syncthreads();
+    const int jo = blockIdx.x * SP_THREADS + tid;
+    if (jo >= n) return;
+    float c;
+    if (a.pooling == KVC_POOL_NONE) {
+        c = seg[tid];
+    } else {
+        const int lo = jo - pad < 0 ? 0 : jo - pad;
+        const int hi = jo - pad + a.kernel_size > n ? n : jo - pad + a.kernel_size;
+        if (a.pooling == KVC_POOL_MAX) {
+            c = -__builtin_inff();
+            for (int i = lo; i < hi; ++i) { const float v = seg[i - j0]; c = v > c ? v : c; }
+        } else {
+            float s2 = 0.0f;
+            for (int i = lo; i < hi; ++i) s2 = s2 + seg[i - j0];
+            c = rnd<DT>(s2 / (float)a.kernel_size);
+        }
+    }
+    reinterpret_cast<raw*>(vw.scores)[(int64_t)hb * n + jo] = Dt<DT>::st(c);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host launch
 // ---------------------------------------------------------------------------------------------
 // One workgroup per head (softmax_pool_kernel) when there are enough heads x items to fill the chip (a prompt's layers
@@ -1490,6 +1637,16 @@ static void launch_softmax_pool_t(const ScoreArgs& a, hipStream_t st) {
         if (fused) {
             if (!(m & 6)) return;
             dim3 g((unsigned)(a.bsz * a.n_q_heads), (unsigned)a.n_items);
+            if constexpr (DT != KVC_FP32 && (WV == 16 || WV == 32 || WV == 64)) {   // 16-row workgroups: the logits read once (bit 12: round 2's form)
+                if (a.off_part16 >= 0 && a.q_len >= 16 && a.q_len <= R16_ITERS * SP_THREADS && !(a.stage_mask & 4096) && (m & 6) == 6) {
+                    static LdsCache c_r16 = {};
+                    (void)ensure_lds(reinterpret_cast<const void*>(&softmax_rows16_kernel<DT>), kSoftmaxLds16, c_r16);
+                    hipLaunchKernelGGL((softmax_rows16_kernel<DT>), dim3((unsigned)(a.bsz * a.n_q_heads * (WV / 16)), (unsigned)a.n_items), dim3(SP_THREADS), kSoftmaxLds16, st, a);
+                    const int n_ = a.q_len - a.window;
+                    hipLaunchKernelGGL((softmax_comb16_kernel<DT>), dim3((unsigned)((n_ + SP_THREADS - 1) / SP_THREADS), (unsigned)(a.bsz * a.n_q_heads), (unsigned)a.n_items), dim3(SP_THREADS), 0, st, a);
+                    return;
+                }
+            }
             if constexpr (WV == 8) {                          // chain waves beside worker waves (debug_stage_mask bit 10: round 2's form)
                 if (a.q_len >= 1024 && a.q_len <= WS_ITERS * WS_WORK && !(a.stage_mask & (256 | 1024))) {
                     static LdsCache c_ws = {};

@@ -444,7 +444,8 @@ def test_patched_model_on_gpu_layer_batching(kvc, gpu_device, method, group, mon
 
 @pytest.mark.parametrize("name", ["snap_bf16_maxpool_W8_L1024_D128", "snap_fp16_avgpool_W32_L1024_D128", "snap_bf16_maxpool_W8_L257_D64",
                                   "snap_bf16_avgpool_W32_L96_D128_peaky", "C2_snapkv_8k_bf16", "C2_snapkv_8k_fp16", "C2_snapkv_8k_bf16_W32",
-                                  "C5_pyramidkv_32k_layer0", "pyr_fp32_layer0_L1024", "edge_all_equal_scores_avg_fp32"])
+                                  "C5_pyramidkv_32k_layer0", "pyr_fp32_layer0_L1024", "edge_all_equal_scores_avg_fp32",
+                                  "edge_W64_default_lib"])
 def test_softmax_pool_forms_identical(kvc, gpu_device, name):
     """The softmax + window-sum + pooling stage has two forms — rowsum_kernel + pool_kernel (many workgroups per head)
     and softmax_pool_kernel (one 1024-thread workgroup per head, exponentials kept in registers up to 8k keys,
@@ -453,10 +454,32 @@ def test_softmax_pool_forms_identical(kvc, gpu_device, name):
     m = G.MANIFEST[name]
     qd, kd, _ = G.inputs(m, device=gpu_device, expanded=False)
     a = kvc.scores(kvc.SNAPKV, qd, kd, m["W"], m["kernel"], m["pooling"], want_intermediates=True, softmax_path="split")
-    for path in ("fused", "fused_r2"):       # at W = 8 and 1 024 <= L <= 8 064 "fused" is the chain-wave / worker-wave kernel of round 3
+    # "fused" is round 3's kernel where one applies (W = 8, 1 024 <= L <= 8 064: chain waves beside worker waves; W = 16 / 32 / 64,
+    # 16-bit, 16 <= L <= 8 192: 16 rows per workgroup, the logits read once), "fused_r2" round 2's one-workgroup-per-head kernel
+    for path in ("fused", "fused_r2"):
         b = kvc.scores(kvc.SNAPKV, qd, kd, m["W"], m["kernel"], m["pooling"], want_intermediates=True, softmax_path=path)
         assert torch.equal(G.bits(a[0]), G.bits(b[0]))
         assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32)) and torch.equal(a[3].view(torch.int32), b[3].view(torch.int32))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("W,L,pooling,kernel", [(16, 300, "maxpool", 7), (16, 4099, "avgpool", 5), (32, 2048, "maxpool", 7), (32, 8192, "avgpool", 7),
+                                                (64, 1000, "maxpool", 13), (64, 8000, None, 7), (32, 97, "maxpool", 7)])
+def test_softmax_rows16_equals_one_workgroup_form(kvc, oracle, gpu_device, dtype, W, L, pooling, kernel):
+    """Windows of 16 / 32 / 64 rows (16-bit dtypes, up to 8 192 keys): the softmax stage runs as one workgroup per 16 ROWS of a
+    head that keeps their logits in registers and reads them once (softmax_rows16_kernel; the window sum is torch's cascade
+    with 16-row leaves, combined in order by softmax_comb16_kernel).  Scores, row maxima and row sums equal the
+    one-workgroup-per-head kernel's (debug_stage_mask bit 12) and the two-kernel form's bit for bit; small cases also the oracle's."""
+    q, k, v = G.synth.make_qkv(8, 2, L, 128, dtype, 3300 + L + W, device=gpu_device)
+    new = kvc.scores(kvc.SNAPKV, q, k, W, kernel, pooling, want_intermediates=True, softmax_path="fused")
+    for path in ("fused_r2", "split"):
+        old = kvc.scores(kvc.SNAPKV, q, k, W, kernel, pooling, want_intermediates=True, softmax_path=path)
+        assert torch.equal(G.bits(new[0]), G.bits(old[0]))
+        assert torch.equal(new[2].view(torch.int32), old[2].view(torch.int32)) and torch.equal(new[3].view(torch.int32), old[3].view(torch.int32))
+    if L <= 2048:
+        sc_o = oracle.scores(q.cpu(), k.cpu(), W, kernel, pooling or "avgpool", dot_mode=oracle.DOT_CHAIN, sum_mode=oracle.SUM_TORCH16) if pooling else None
+        if sc_o is not None:
+            assert torch.equal(G.bits(new[0][0]), G.bits(sc_o))
 
 
 def _tie_heavy_scores(heads, n, dtype, seed, levels):
