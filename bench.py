@@ -8,7 +8,7 @@ consecutive prompts (default per config, chosen so that the K timed steps last a
 utilisation sampler and its wall clock can see them), cycling over `--sets` distinct resident prompts so the K working
 set (0.5 GB per prompt at 8k) is never cache resident.  tokens/step = prompts * q_len * 32 layers.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2_w32|c3|c4|c5] [--tie-mode torch_cpu|canonical]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2_w16|c2_w32|c2_w64|c3|c4|c5] [--tie-mode torch_cpu|canonical]
                     [--mode batch|calls] [--in-flight 1..4]
 
 N > 1 (torchrun, one rank per GPU): the path shards by independent prompts/layers with no exchange, so every rank
@@ -40,6 +40,10 @@ CONFIGS = {
                desc="SnapKV Llama-3-8B shapes (Hq=32,Hkv=8,D=128), seq_len=8000 -> max_capacity_prompt=128, bf16, W=8, maxpool7"),
     "c2_w32": dict(method="snapkv", L=8000, cap=128, W=32, kernel=7, pooling="maxpool", dtype=torch.bfloat16, prompts=16,
                    desc="SnapKV 8k->128, W=32 (needle-runner window)"),
+    "c2_w16": dict(method="snapkv", L=8000, cap=128, W=16, kernel=7, pooling="maxpool", dtype=torch.bfloat16, prompts=24,
+                   desc="SnapKV 8k->128, W=16 (two M-tiles per KV head; cap - W = 112 kept)"),
+    "c2_w64": dict(method="snapkv", L=8000, cap=128, W=64, kernel=7, pooling="maxpool", dtype=torch.bfloat16, prompts=8,
+                   desc="SnapKV 8k->128, W=64 (the library's window default; cap - W = 64 kept)"),
     "c4": dict(method="pyramidkv", L=8000, cap=128, W=8, kernel=7, pooling="maxpool", dtype=torch.bfloat16, prompts=32,
                desc="PyramidKV 8k, total budget 128x32 (k_l = 234..17)"),
     "c5": dict(method="pyramidkv", L=32000, cap=2048, W=8, kernel=7, pooling="maxpool", dtype=torch.bfloat16, prompts=6, sets=1,
