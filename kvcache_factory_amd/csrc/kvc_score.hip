@@ -467,14 +467,16 @@ __global__ __launch_bounds__(LOGITS_THREADS, 3) void logits_kernel(const ScoreAr
                 // the branch-free scaling needs every |value| of the tile inside [2^-98, 2^126] (rounding to dtype moves a
                 // value by < 1 %, so this keeps the rounded value inside the proven [2^-100, inf) guard); a zero logit, an
                 // overflow or a NaN sends the whole tile down the general path instead
-                uint32_t amin = f2u(acc[0]) & 0x7fffffffu, amax = amin;
+                // (v_min3_f32 / v_max3_f32 take |x| as a source modifier: 16 instructions where integer compares on the masked bits
+                // took 48.  They skip a NaN — which the packed path turns into a NaN like the general one, and NaN scores all
+                // order alike; an infinity is caught by the maximum.)
+                float amin = __builtin_fminf(__builtin_fabsf(acc[0]), __builtin_fabsf(acc[1])), amax = __builtin_fmaxf(__builtin_fabsf(acc[0]), __builtin_fabsf(acc[1]));
 #pragma unroll
-                for (int e = 1; e < 16; ++e) {
-                    const uint32_t t = f2u(acc[e]) & 0x7fffffffu;
-                    amin = t < amin ? t : amin;
-                    amax = t > amax ? t : amax;
+                for (int e = 2; e < 16; e += 2) {
+                    amin = __builtin_fminf(__builtin_fminf(__builtin_fabsf(acc[e]), __builtin_fabsf(acc[e + 1])), amin);
+                    amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(acc[e]), __builtin_fabsf(acc[e + 1])), amax);
                 }
-                plain = !__any(!(amin >= 0x0e800000u && amax <= 0x7e800000u));
+                plain = !__any(!(amin >= u2f(0x0e800000u) && amax <= u2f(0x7e800000u)));
             }
             if (plain) {                                        // branch-free epilogue, two accumulator elements at a time
                 const uint32_t keyoff = (uint32_t)(tile * 32 + j) * (uint32_t)(W * ES);
@@ -819,14 +821,16 @@ __global__ __launch_bounds__(LOGITS_THREADS, 2) void logits_mt4_kernel(const Sco
                 // the branch-free scaling needs every |value| of the tile inside [2^-98, 2^126] (rounding to dtype moves a
                 // value by < 1 %, so this keeps the rounded value inside the proven [2^-100, inf) guard); a zero logit, an
                 // overflow or a NaN sends the whole tile down the general path instead
-                uint32_t amin = f2u(acc[0]) & 0x7fffffffu, amax = amin;
+                // (v_min3_f32 / v_max3_f32 take |x| as a source modifier: 16 instructions where integer compares on the masked bits
+                // took 48.  They skip a NaN — which the packed path turns into a NaN like the general one, and NaN scores all
+                // order alike; an infinity is caught by the maximum.)
+                float amin = __builtin_fminf(__builtin_fabsf(acc[0]), __builtin_fabsf(acc[1])), amax = __builtin_fmaxf(__builtin_fabsf(acc[0]), __builtin_fabsf(acc[1]));
 #pragma unroll
-                for (int e = 1; e < 16; ++e) {
-                    const uint32_t t = f2u(acc[e]) & 0x7fffffffu;
-                    amin = t < amin ? t : amin;
-                    amax = t > amax ? t : amax;
+                for (int e = 2; e < 16; e += 2) {
+                    amin = __builtin_fminf(__builtin_fminf(__builtin_fabsf(acc[e]), __builtin_fabsf(acc[e + 1])), amin);
+                    amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(acc[e]), __builtin_fabsf(acc[e + 1])), amax);
                 }
-                plain = !__any(!(amin >= 0x0e800000u && amax <= 0x7e800000u));
+                plain = !__any(!(amin >= u2f(0x0e800000u) && amax <= u2f(0x7e800000u)));
             }
             if (plain) {                                        // branch-free epilogue, two accumulator elements at a time
                 const uint32_t keyoff = (uint32_t)(tile * 32 + j) * (uint32_t)(W * ES);
