@@ -1,5 +1,9 @@
+"""Run-to-run check of the fused H2O kernel against round 2's materialising kernels (debug_stage_mask bit 11): twelve repeats of four
+shapes, fp16 and bf16.  This is the script that showed the fp16 path's write-after-read on the K ring (one head off by a unit in the
+last place in one run of five) before tests/test_gpu_parity.py::test_h2o_fused_same_bits_every_run pinned it."""
 import sys, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kvcache_factory_amd import _kvc as kvc, synth
 dev = torch.device("cuda:0")
 for rep in range(12):
