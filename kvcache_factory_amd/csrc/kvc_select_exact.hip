@@ -18,6 +18,7 @@
 //
 // One wave per head: the run time is the latency of that head's chain of moves, not a throughput; the canonical
 // path (kvc_select.hip) is the fast one.
+#include <stdlib.h>
 #include "kvc_common.h"
 #include "kvc_launch.h"
 #include "kvc_stl_emul.h"
@@ -1466,7 +1467,9 @@ static int launch_exact_t(const SelectArgs& a, void* scratch, hipStream_t st) {
     // LDS sized for the worst item: a heap of k_max (partial_sort regime) or the whole array (nth_element regime)
     bool any_nth = false;
     for (int i = 0; i < a.n_items; ++i) any_nth = any_nth || !((int64_t)a.k.v[i] * 64 <= (int64_t)a.n);
-    const int in_lds = !any_nth || a.n <= 18000;
+    int lds_max_n = 18000;
+    if (const char* e = getenv("KVC_EXACT_LDS_MAXN")) { const long v = atol(e); if (v >= 1024 && v <= 36000) lds_max_n = (int)v; }   // tuning aid
+    const int in_lds = !any_nth || a.n <= lds_max_n;
     // LDS: the whole array (nth_element items, n <= 18000), or the heap of k_max (partial_sort) / the k_max - 1 elements
     // being sorted; behind it the list region of the partitions, as large as the resident workgroups per CU allow (160 KB
     // of LDS, one wave = one workgroup here: these kernels are latency-bound, a second round of workgroups doubles
