@@ -344,6 +344,39 @@ def test_batched_layers_equal_per_layer_calls(kvc, gpu_device, tie):
         assert torch.equal(bp.idx[l], i1) and torch.equal(ko[l], k1) and torch.equal(vo[l], v1)
 
 
+def test_prefill_batch_overlapped_flush_without_owner_buffers(kvc, gpu_device):
+    """Round-2 advisor finding: PrefillBatch.flush(overlap=True) hands FRESH tensors to a sink when an entry came without
+    `alloc`; a sink that copies them on the main stream must not read them while the side stream is still writing.  Such
+    groups are therefore compressed on the caller's stream (only groups whose outputs go into owner-provided buffers
+    overlap).  Mixed here: two entries with owner buffers, two without, sinks that copy at once on the current stream —
+    every copy equals the per-layer kvc.compress result, over several repetitions with busy-work queued in front."""
+    from kvcache_factory_amd import pyramidkv_utils as pu
+    from kvcache_factory_amd.cache import CompressedDynamicLayer
+    L, W, cap = 4000, 8, 72
+    cl = pu.SnapKVCluster(window_size=W, max_capacity_prompt=cap, kernel_size=7, pooling="maxpool")
+    for rep in range(4):
+        qkv = [G.synth.make_qkv(8, 2, L, 128, torch.bfloat16, 8800 + 10 * rep + i, device=gpu_device) for i in range(4)]
+        want = [kvc.compress(kvc.SNAPKV, q, k, v, W, cap - W, 7, "maxpool", "torch_cpu") for q, k, v in qkv]
+        got, layers = {}, [CompressedDynamicLayer(), CompressedDynamicLayer()]
+        pb = pu.PrefillBatch()
+        junk = torch.randn(4096, 4096, device=gpu_device)
+        for _ in range(3):
+            junk = junk @ junk * 1e-3                               # the main stream is busy when the flush is issued
+        for i, (q, k, v) in enumerate(qkv):
+            if i < 2:
+                assert pb.add(cl, k, q, v, lambda kc, vc, i=i: (layers[i].prefill(kc, vc, L), got.__setitem__(i, (kc, vc))), tag=i, alloc=layers[i].reserve)
+            else:
+                assert pb.add(cl, k, q, v, lambda kc, vc, i=i: got.__setitem__(i, (kc.clone(), vc.clone())), tag=i)   # copies at once
+            if len(pb) == 2:
+                pb.flush(overlap=True)
+        pb.settle()
+        torch.cuda.synchronize(gpu_device)
+        for i in range(4):
+            kw, vw = want[i][0], want[i][1]
+            kg, vg = got[i]                                          # (i < 2: views of the layer's own buffers, read after settle())
+            assert torch.equal(G.bits(kg), G.bits(kw)) and torch.equal(G.bits(vg), G.bits(vw)), (rep, i)
+
+
 @pytest.mark.parametrize("name", ["snap_bf16_maxpool_W8_L1024_D128", "snap_fp16_avgpool_W32_L1024_D128", "snap_bf16_maxpool_W8_L257_D64",
                                   "C2_snapkv_8k_bf16", "C2_snapkv_8k_fp16", "C2_snapkv_8k_bf16_peaky", "C4_pyramidkv_8k_layer0"])
 def test_fast_dot_mode_within_tolerance(kvc, gpu_device, name):
