@@ -192,6 +192,21 @@ def test_h2o_fused_equals_materialising_form(kvc, oracle, gpu_device, dtype, hq,
         assert torch.equal(G.bits(fused[0]), G.bits(sc_o))
 
 
+@pytest.mark.parametrize("hq,hkv", [(8, 8), (6, 2)])
+def test_round3_kernels_with_a_batch_dimension(kvc, gpu_device, hq, hkv):
+    """bsz = 2 through the kernels added in round 3 — their workgroup -> (batch, head, block) maps (XCD-aware when the head count
+    is a multiple of 8, plain otherwise): the fused H2O kernel and the 16-row softmax form give, per batch row, the bits of
+    the same prompt run alone."""
+    L, W = 1100, 32
+    one = [G.synth.make_qkv(hq, hkv, L, 128, torch.bfloat16, 6100 + i, device=gpu_device) for i in range(2)]
+    q2, k2 = torch.cat([o[0] for o in one]), torch.cat([o[1] for o in one])
+    for method, pooling in ((kvc.H2O, None), (kvc.SNAPKV, "maxpool")):
+        both = kvc.scores(method, q2, k2, W, 7, pooling)
+        for b in range(2):
+            alone = kvc.scores(method, one[b][0], one[b][1], W, 7, pooling)
+            assert torch.equal(G.bits(both[b]), G.bits(alone[0])), (method, b)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_h2o_fused_same_bits_every_run(kvc, gpu_device, dtype):
     """The fused kernel moves K global -> LDS with hand-issued global_load_lds and reads it with loads the compiler does not
