@@ -1218,6 +1218,46 @@ struct WaveHeap9 {
         M = __ballot(N::gt(xr, xl));
         force_bit(len);
     }
+    // adjust<true>(0, 0, len, value) — the step of __heap_select and __sort_heap — without a branch: a branch costs a lone wave
+    // ~40 cycles taken or not (tools/hop_probe.hip) and the general form above compiles to fifteen of them per step (the
+    // private walk, its three depths, the exits of the top part); here every choice is a select, the private walk always runs
+    // and the lane it concerns is picked afterwards.  Same moves, same array (test_compress_exact_ties_*, every C5 layer).
+    __device__ __forceinline__ void adjust_top(int len, uint32_t value) {
+        const u64 in_top = len >= 63 ? 0x7fffffffffffffffull : ((1ull << len) - 1);
+        const u64 on_top = __ballot(((M ^ R) & A) == 0) & in_top;
+        const u64 m5 = on_top & 0x7fffffff80000000ull;                 // the on-path level-5 node, if the path gets there
+        const int l5 = __builtin_ctzll(m5 | (1ull << 63));
+        const int c6 = 2 * l5 + 2 - (int)((M >> l5) & 1);
+        const bool leaves = m5 != 0 && c6 < len;                       // the path leaves the top part, into lane j6's sub-heap
+        const int j6 = leaves ? c6 - 63 : 0;
+        walk(len);
+        const int spj = __builtin_amdgcn_readlane(private_stop(value, true), j6);
+        const int sp = leaves ? spj : -1;
+        const u64 g = __ballot(N::gt(top, value));
+        const u64 c_top = on_top & ~g & ~1ull;
+        const int stop = 63 - __builtin_clzll(c_top | 1ull);           // (bit 0 is never in c_top: no path node -> the root)
+        const u64 below = (1ull << stop) - 1;
+        const u64 take = sp >= 0 ? on_top : (on_top & below);
+        const u64 eq = sp >= 0 ? 0ull : (1ull << stop);
+        const uint32_t child = lane_sel(xr, xl, M);
+        uint32_t vv = value;
+        asm volatile("" : "+v"(vv));
+        top = lane_sel(lane_sel(top, child, take), vv, eq);
+        const bool mine = sp >= 0 && lane == j6;                       // private_apply(sp, value, mine) as selects
+        const uint32_t np0 = sp == 0 ? value : v1, w1 = sp == 1 ? value : v2;
+        const bool m1 = mine && sp >= 1, m2 = mine && sp >= 2;
+        p0 = mine ? np0 : p0;
+        p1 = (m1 && d1 == 1) ? w1 : p1; p2 = (m1 && d1 == 2) ? w1 : p2;
+        p3 = (m2 && d2 == 3) ? value : p3; p4 = (m2 && d2 == 4) ? value : p4;
+        p5 = (m2 && d2 == 5) ? value : p5; p6 = (m2 && d2 == 6) ? value : p6;
+        arr[lane] = top;                                               // (lane 63 has no top node: its store to arr[63] is overwritten
+        arr[63 + lane] = p0;                                           //  by lane 0's p0 right behind it — one wave, LDS in order)
+        asm volatile("" ::: "memory");
+        xl = arr[2 * lane + 1]; xr = arr[2 * lane + 2];
+        M = __ballot(N::gt(xr, xl));
+        const bool fb = len >= 2 && (len & 1) == 0 && ((len - 2) >> 1) < 63;
+        M |= fb ? (1ull << (((len - 2) >> 1) & 63)) : 0ull;
+    }
 };
 
 // std::partial_sort for 128 < k <= 511 (16-bit dtypes).
@@ -1257,7 +1297,7 @@ __device__ __forceinline__ void partial_sort_wave9(const typename Dt<DT>::raw* s
                 pending &= pending - 1;
                 const uint32_t kk = __builtin_amdgcn_readlane(cur[j], src);
                 if (kk > root) {
-                    H.adjust<true>(0, 0, k, N::make(kk, i0 + src));
+                    H.adjust_top(k, N::make(kk, i0 + src));
                     root = N::key(N::rdlane(H.top, 0));
                 }
             }
@@ -1271,7 +1311,7 @@ __device__ __forceinline__ void partial_sort_wave9(const typename Dt<DT>::raw* s
         const uint32_t value = H.node(last), topv = N::rdlane(H.top, 0);
         if (lane == 0) res[last] = topv;
         H.force_bit(last);
-        H.adjust<true>(0, 0, last, value);
+        H.adjust_top(last, value);
     }
     if (lane == 0) res[0] = H.top;
     __syncthreads();
