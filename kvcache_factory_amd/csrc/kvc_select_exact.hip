@@ -1223,17 +1223,22 @@ struct WaveHeap9 {
     // private walk, its three depths, the exits of the top part); here every choice is a select, the private walk always runs
     // and the lane it concerns is picked afterwards.  Same moves, same array (test_compress_exact_ties_*, every C5 layer).
     __device__ __forceinline__ void adjust_top(int len, uint32_t value) {
+        // (the vector work whose results the scalar chain below needs goes first: each ballot / readlane is a VALU -> SALU
+        // hand-off of 20-35 cycles, and three of them in a row wait for each other only if they are issued one by one)
+        walk(len);
+        int ps = private_stop(value, true);
+        const u64 g = __ballot(N::gt(top, value));
         const u64 in_top = len >= 63 ? 0x7fffffffffffffffull : ((1ull << len) - 1);
-        const u64 on_top = __ballot(((M ^ R) & A) == 0) & in_top;
+        // (ancestors of the top nodes are nodes 0..30: the low words of A, R and M decide)
+        const u64 on_top = __ballot((((uint32_t)M ^ (uint32_t)R) & (uint32_t)A) == 0) & in_top;
+        asm volatile("" : "+v"(ps));
         const u64 m5 = on_top & 0x7fffffff80000000ull;                 // the on-path level-5 node, if the path gets there
         const int l5 = __builtin_ctzll(m5 | (1ull << 63));
         const int c6 = 2 * l5 + 2 - (int)((M >> l5) & 1);
         const bool leaves = m5 != 0 && c6 < len;                       // the path leaves the top part, into lane j6's sub-heap
         const int j6 = leaves ? c6 - 63 : 0;
-        walk(len);
-        const int spj = __builtin_amdgcn_readlane(private_stop(value, true), j6);
+        const int spj = __builtin_amdgcn_readlane(ps, j6);
         const int sp = leaves ? spj : -1;
-        const u64 g = __ballot(N::gt(top, value));
         const u64 c_top = on_top & ~g & ~1ull;
         const int stop = 63 - __builtin_clzll(c_top | 1ull);           // (bit 0 is never in c_top: no path node -> the root)
         const u64 below = (1ull << stop) - 1;
