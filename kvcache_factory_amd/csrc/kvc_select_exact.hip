@@ -1080,6 +1080,7 @@ struct WaveHeap9 {
     uint32_t xl, xr;       // its children
     uint32_t p0, p1, p2, p3, p4, p5, p6;   // private sub-heap of lane j: nodes 63+j; 127+2j, 128+2j; 255+4j..258+4j
     u64 A, R, M;
+    u64 A9, R9;            // the same for this lane's level-6 node 63 + lane (adjust_top)
     uint32_t* arr;
     int lane;
     // what the private walk of this lane found for the current step (valid for every lane, used for one)
@@ -1171,6 +1172,8 @@ struct WaveHeap9 {
         arr = lds;
         A = R = 0;
         for (int c = lane; c > 0;) { const int p = (c - 1) >> 1; A |= 1ull << p; if (c & 1) R |= 1ull << p; c = p; }
+        A9 = R9 = 0;
+        for (int c = 63 + lane; c > 0;) { const int p = (c - 1) >> 1; A9 |= 1ull << p; if (c & 1) R9 |= 1ull << p; c = p; }
         private_make_heap(len);
         if (lane < 63) arr[lane] = top;
         arr[63 + lane] = p0;
@@ -1223,34 +1226,25 @@ struct WaveHeap9 {
     // private walk, its three depths, the exits of the top part); here every choice is a select, the private walk always runs
     // and the lane it concerns is picked afterwards.  Same moves, same array (test_compress_exact_ties_*, every C5 layer).
     __device__ __forceinline__ void adjust_top(int len, uint32_t value) {
-        // (the vector work whose results the scalar chain below needs goes first: each ballot / readlane is a VALU -> SALU
-        // hand-off of 20-35 cycles, and three of them in a row wait for each other only if they are issued one by one)
+        // Every lane decides for itself, as top node `lane` and as the owner of level-6 node 63 + lane: is my node on the sift path
+        // (its ancestors' choices, the bits of M, all point to it)?  The one thing that needs the other lanes is "does the value
+        // land deeper than me" — one ballot of the path nodes that do not sort before the value (and one for the private part),
+        // read back as a vector operand.  No readlane, no scalar chain, no branch.
         walk(len);
-        int ps = private_stop(value, true);
-        const u64 g = __ballot(N::gt(top, value));
-        const u64 in_top = len >= 63 ? 0x7fffffffffffffffull : ((1ull << len) - 1);
-        // (ancestors of the top nodes are nodes 0..30: the low words of A, R and M decide)
-        const u64 on_top = __ballot((((uint32_t)M ^ (uint32_t)R) & (uint32_t)A) == 0) & in_top;
-        asm volatile("" : "+v"(ps));
-        const u64 m5 = on_top & 0x7fffffff80000000ull;                 // the on-path level-5 node, if the path gets there
-        const int l5 = __builtin_ctzll(m5 | (1ull << 63));
-        const int c6 = 2 * l5 + 2 - (int)((M >> l5) & 1);
-        const bool leaves = m5 != 0 && c6 < len;                       // the path leaves the top part, into lane j6's sub-heap
-        const int j6 = leaves ? c6 - 63 : 0;
-        const int spj = __builtin_amdgcn_readlane(ps, j6);
-        const int sp = leaves ? spj : -1;
-        const u64 c_top = on_top & ~g & ~1ull;
-        const int stop = 63 - __builtin_clzll(c_top | 1ull);           // (bit 0 is never in c_top: no path node -> the root)
-        const u64 below = (1ull << stop) - 1;
-        const u64 take = sp >= 0 ? on_top : (on_top & below);
-        const u64 eq = sp >= 0 ? 0ull : (1ull << stop);
+        const int ps = private_stop(value, true);                          // this lane's private sub-heap, if the path enters it
+        const bool on = ((((uint32_t)M ^ (uint32_t)R) & (uint32_t)A) == 0) && lane < 63 && lane < len;   // (ancestors of the top nodes: 0..30)
+        const bool on9 = (((M ^ R9) & A9) == 0) && 63 + lane < len;
+        const bool g = N::gt(top, value);
+        const u64 c = __ballot(on && !g && lane != 0);                     // path nodes the value may stop at (the root: fallback)
+        const u64 d = __ballot(on9 && ps >= 0);                            // ... inside the private part (at most one lane)
+        const u64 deeper = (c | (d != 0 ? (1ull << 63) : 0ull)) >> 1;      // bit i: a stopping place at top node i + 1, or private
+        const bool dx = (deeper >> lane) != 0;                             // ... deeper than top node `lane`
+        const bool take = on && dx, eq = on && !dx && (lane == 0 || !g);
         const uint32_t child = lane_sel(xr, xl, M);
-        uint32_t vv = value;
-        asm volatile("" : "+v"(vv));
-        top = lane_sel(lane_sel(top, child, take), vv, eq);
-        const bool mine = sp >= 0 && lane == j6;                       // private_apply(sp, value, mine) as selects
-        const uint32_t np0 = sp == 0 ? value : v1, w1 = sp == 1 ? value : v2;
-        const bool m1 = mine && sp >= 1, m2 = mine && sp >= 2;
+        top = eq ? value : (take ? child : top);
+        const bool mine = on9 && ps >= 0;                                  // private_apply(ps, value, mine) as selects
+        const uint32_t np0 = ps == 0 ? value : v1, w1 = ps == 1 ? value : v2;
+        const bool m1 = mine && ps >= 1, m2 = mine && ps >= 2;
         p0 = mine ? np0 : p0;
         p1 = (m1 && d1 == 1) ? w1 : p1; p2 = (m1 && d1 == 2) ? w1 : p2;
         p3 = (m2 && d2 == 3) ? value : p3; p4 = (m2 && d2 == 4) ? value : p4;
