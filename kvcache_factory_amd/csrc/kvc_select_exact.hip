@@ -1229,31 +1229,53 @@ struct WaveHeap9 {
         // Every lane decides for itself, as top node `lane` and as the owner of level-6 node 63 + lane: is my node on the sift path
         // (its ancestors' choices, the bits of M, all point to it)?  The one thing that needs the other lanes is "does the value
         // land deeper than me" — one ballot of the path nodes that do not sort before the value (and one for the private part),
-        // read back as a vector operand.  No readlane, no scalar chain, no branch.
-        walk(len);
-        const int ps = private_stop(value, true);                          // this lane's private sub-heap, if the path enters it
-        const bool on = ((((uint32_t)M ^ (uint32_t)R) & (uint32_t)A) == 0) && lane < 63 && lane < len;   // (ancestors of the top nodes: 0..30)
-        const bool on9 = (((M ^ R9) & A9) == 0) && 63 + lane < len;
-        const bool g = N::gt(top, value);
-        const u64 c = __ballot(on && !g && lane != 0);                     // path nodes the value may stop at (the root: fallback)
-        const u64 d = __ballot(on9 && ps >= 0);                            // ... inside the private part (at most one lane)
-        const u64 deeper = (c | (d != 0 ? (1ull << 63) : 0ull)) >> 1;      // bit i: a stopping place at top node i + 1, or private
-        const bool dx = (deeper >> lane) != 0;                             // ... deeper than top node `lane`
-        const bool take = on && dx, eq = on && !dx && (lane == 0 || !g);
+        // read back as vector operands.  No readlane, no scalar chain, no branch — and no `&&` of two per-lane conditions: the
+        // compiler turns each into an s_and_b64 between the v_cmp that made them and the v_cndmask that uses them (~20 cycles per
+        // hand-off, ~25 of them in the first branch-free form).  Conditions are folded into the VALUES that are compared instead
+        // (an absent node is all ones, an excluded lane compares as zero), so every select hangs on ONE fresh compare.
+        const uint32_t vor = value | 0xffffu, ones = 0xffffffffu;
+        auto absent = [](int idx, int len_) -> uint32_t { return (uint32_t)((len_ - 1 - idx) >> 31); };   // 0xffffffff if idx >= len_, else 0
+        // ---- the private walk (walk(len) + private_stop(value, true)), this lane's sub-heap ----
+        const int a1 = q1(), a3 = q3();
+        const bool r1 = (p2 | absent(a1 + 1, len)) <= (p1 | 0xffffu);  // move right at level 7: the right child exists and does not sort before the left
+        d1 = r1 ? 2 : 1;
+        v1 = r1 ? p2 : p1;
+        const uint32_t cl = r1 ? p5 : p3, cr = r1 ? p6 : p4;
+        const int al = r1 ? a3 + 2 : a3;
+        const bool r2 = (cr | absent(al + 1, len)) <= (cl | 0xffffu);
+        d2 = (r1 ? 5 : 3) + (r2 ? 1 : 0);
+        v2 = r2 ? cr : cl;
+        const uint32_t no1 = absent(a1, len), no2 = no1 | absent(al, len);
+        int ps = (p0 <= vor) ? 0 : -1;                                 // deepest private path node that does not sort before the value
+        ps = ((v1 | no1) <= vor) ? 1 : ps;
+        ps = ((v2 | no2) <= vor) ? 2 : ps;
+        // ---- on the path? ----
+        const int lim = len < 63 ? len : 63;
+        const uint32_t t_on = (((uint32_t)M ^ (uint32_t)R) & (uint32_t)A) | absent(lane, lim);          // 0: top node `lane` is on the path
+        const u64 t9w = (M ^ R9) & A9;
+        const uint32_t t_on9 = (uint32_t)t9w | (uint32_t)(t9w >> 32) | absent(63 + lane, len);            // 0: level-6 node 63 + lane is
+        const uint32_t lane0 = lane == 0 ? ones : 0u;
+        const uint32_t cand = (t_on | lane0) == 0 ? top : ones;        // (the root is the fallback, not a candidate)
+        const u64 c = __ballot(cand <= vor);                           // path nodes the value may stop at
+        const int code = t_on9 == 0 ? ps : -1;                         // private stop of the ONE lane whose sub-heap the path enters
+        const u64 d = __ballot(code >= 0);
+        const u64 cs = c >> 1;
+        const u64 dxw = (cs >> lane) | d;                              // != 0: the value lands deeper than top node `lane`
         const uint32_t child = lane_sel(xr, xl, M);
-        top = eq ? value : (take ? child : top);
-        const bool mine = on9 && ps >= 0;                                  // private_apply(ps, value, mine) as selects
-        const uint32_t np0 = ps == 0 ? value : v1, w1 = ps == 1 ? value : v2;
-        const bool m1 = mine && ps >= 1, m2 = mine && ps >= 2;
-        p0 = mine ? np0 : p0;
-        p1 = (m1 && d1 == 1) ? w1 : p1; p2 = (m1 && d1 == 2) ? w1 : p2;
-        p3 = (m2 && d2 == 3) ? value : p3; p4 = (m2 && d2 == 4) ? value : p4;
-        p5 = (m2 && d2 == 5) ? value : p5; p6 = (m2 && d2 == 6) ? value : p6;
+        const uint32_t va = (top & ~lane0) <= vor ? value : top;       // it lands here if nothing deeper takes it (the root: always)
+        const uint32_t vb = dxw != 0 ? child : va;
+        top = t_on == 0 ? vb : top;
+        // ---- private_apply(code, value) ----
+        const uint32_t np0 = code == 0 ? value : v1, w1 = code == 1 ? value : v2;
+        p0 = code >= 0 ? np0 : p0;
+        const int z1 = code >= 1 ? d1 : 0, z2 = code >= 2 ? d2 : 0;
+        p1 = z1 == 1 ? w1 : p1; p2 = z1 == 2 ? w1 : p2;
+        p3 = z2 == 3 ? value : p3; p4 = z2 == 4 ? value : p4; p5 = z2 == 5 ? value : p5; p6 = z2 == 6 ? value : p6;
         arr[lane] = top;                                               // (lane 63 has no top node: its store to arr[63] is overwritten
         arr[63 + lane] = p0;                                           //  by lane 0's p0 right behind it — one wave, LDS in order)
         asm volatile("" ::: "memory");
         xl = arr[2 * lane + 1]; xr = arr[2 * lane + 2];
-        M = __ballot(N::gt(xr, xl));
+        M = __ballot(xr > (xl | 0xffffu));
         const bool fb = len >= 2 && (len & 1) == 0 && ((len - 2) >> 1) < 63;
         M |= fb ? (1ull << (((len - 2) >> 1) & 63)) : 0ull;
     }
